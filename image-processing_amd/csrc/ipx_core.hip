@@ -1,0 +1,99 @@
+// ipx_core.hip -- error plumbing, argument validation and host-side helpers of libipx.
+#include "ipx_common.h"
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+int ipx_fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+void ipx_clear_error() { g_err[0] = 0; }
+
+int ipx_check_image_args(const char* fn, const void* src, const void* dst, int n, int h, int w,
+                         int src_c, int dst_c, int64_t src_row_stride, int64_t src_img_stride,
+                         int64_t dst_row_stride, int64_t dst_img_stride)
+{
+    ipx_clear_error();
+    if (!src || !dst) return ipx_fail(IPX_ERR_INVALID, "%s: null image pointer", fn);
+    if (n <= 0 || h <= 0 || w <= 0) return ipx_fail(IPX_ERR_INVALID, "%s: n=%d h=%d w=%d must be positive", fn, n, h, w);
+    if (src_c < 1 || src_c > 4 || dst_c < 1 || dst_c > 4)
+        return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: channel count %d/%d outside 1..4", fn, src_c, dst_c);
+    if ((int64_t)w * 4 > 0x7fffffff) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: w=%d too large", fn, w);
+    if (src_row_stride < (int64_t)w * src_c) return ipx_fail(IPX_ERR_INVALID, "%s: src_row_stride %lld < %lld row bytes", fn, (long long)src_row_stride, (long long)w * src_c);
+    if (dst_row_stride < (int64_t)w * dst_c) return ipx_fail(IPX_ERR_INVALID, "%s: dst_row_stride %lld < %lld row bytes", fn, (long long)dst_row_stride, (long long)w * dst_c);
+    if (n > 1) {
+        if (src_img_stride < src_row_stride * (int64_t)(h - 1) + (int64_t)w * src_c)
+            return ipx_fail(IPX_ERR_INVALID, "%s: src_img_stride %lld smaller than one image", fn, (long long)src_img_stride);
+        if (dst_img_stride < dst_row_stride * (int64_t)(h - 1) + (int64_t)w * dst_c)
+            return ipx_fail(IPX_ERR_INVALID, "%s: dst_img_stride %lld smaller than one image", fn, (long long)dst_img_stride);
+    }
+    return IPX_OK;
+}
+
+extern "C" {
+
+int ipx_version(void) { return 100; /* 0.1.0 */ }
+
+const char* ipx_last_error(void) { return g_err; }
+
+int ipx_check_device(void)
+{
+    ipx_clear_error();
+    int dev = 0;
+    IPX_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    IPX_HIP(hipGetDeviceProperties(&p, dev));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return ipx_fail(IPX_ERR_UNSUPPORTED, "device %d is %s; libipx is built for gfx950 only", dev, p.gcnArchName);
+    return IPX_OK;
+}
+
+// Q0.8 Gaussian taps as cv2.GaussianBlur builds them for uint8 input (server.py:428):
+// OpenCV smooth.dispatch.cpp getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED.
+int ipx_gauss_kernel_q8(int k, double sigma, uint16_t* out)
+{
+    ipx_clear_error();
+    if (!out) return ipx_fail(IPX_ERR_INVALID, "ipx_gauss_kernel_q8: null output");
+    if (k < 1 || (k & 1) == 0 || k > IPX_MAX_GAUSS_K)
+        return ipx_fail(IPX_ERR_INVALID, "ipx_gauss_kernel_q8: k=%d must be odd and in 1..%d", k, IPX_MAX_GAUSS_K);
+    std::vector<double> f(k);
+    static const double t3[] = {0.25, 0.5, 0.25};
+    static const double t5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625};
+    static const double t7[] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
+    static const double t9[] = {4 / 256., 13 / 256., 30 / 256., 51 / 256., 60 / 256., 51 / 256., 30 / 256., 13 / 256., 4 / 256.};
+    const double* tab = nullptr;
+    if (sigma <= 0) tab = k == 3 ? t3 : k == 5 ? t5 : k == 7 ? t7 : k == 9 ? t9 : nullptr;
+    if (k == 1 && sigma <= 0) { out[0] = 256; return IPX_OK; }
+    if (tab) {
+        for (int i = 0; i < k; ++i) f[i] = tab[i];
+    } else {
+        const double sg = sigma > 0 ? sigma : 0.15 * k + 0.35;
+        const double scale2 = -0.5 / (sg * sg);
+        double sum = 0;
+        for (int i = 0; i < k; ++i) { const double x = i - (k - 1) * 0.5; f[i] = exp(scale2 * x * x); sum += f[i]; }
+        for (int i = 0; i < k; ++i) f[i] /= sum;
+    }
+    double err = 0;
+    long acc = 0;
+    for (int i = 0; i < k / 2; ++i) {           // error diffusion from the ends inward
+        const double adj = f[i] * 256.0 + err;
+        const long v0 = lrint(adj);              // cvRound
+        err = adj - (double)v0;
+        out[i] = out[k - 1 - i] = (uint16_t)v0;
+        acc += v0;
+    }
+    out[k / 2] = (uint16_t)(256 - 2 * acc);      // centre tap closes the sum to exactly 256
+    return IPX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+// ipx_hist.hip -- 256-bin histogram, equalizeHist LUT construction, cv2.equalizeHist.
+//
+// hist_partial_kernel: each block counts a slice of one image into an LDS histogram laid out
+//   [256 bins][32 copies] (32 KiB): lane l always adds to copy (l & 31), i.e. to LDS bank (l & 31), so a
+//   wave's 64 ds_add_u32 never collide on a bank whatever the pixel values are -- a constant image
+//   (all lanes, one bin) costs the same as white noise.  The 32 copies are folded with a rotated
+//   (conflict-free) read and the block stores its 256 partial counts with plain coalesced stores: no
+//   global atomics, no zero-fill, bitwise reproducible.
+// hist_finish_kernel: one block per image sums the per-block partials and (optionally) builds the
+//   equalization table with an LDS scan, in float32 exactly as OpenCV does.
+#include "ipx_common.h"
+
+extern "C" int ipx_lut_dev_u8(void*, const uint8_t*, uint8_t*, int, int, int, int, int64_t, int64_t, int64_t, int64_t,
+                              const uint8_t*, int64_t);
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 4;
+constexpr int kChunk = kThreads * 16;
+constexpr int kUnit = kChunk * kUnroll;          // 16 KiB of pixels per block step
+constexpr int kCopies = 32;
+
+struct HistGeom {
+    int rows;
+    int64_t len;
+    int64_t s_row, s_img;
+    unsigned units_per_row, units_per_img;
+};
+
+__device__ __forceinline__ void count4(uint32_t* s_hist, uint32_t x, unsigned copy)
+{
+    atomicAdd(&s_hist[((x & 255u) << 5) | copy], 1u);
+    atomicAdd(&s_hist[(((x >> 8) & 255u) << 5) | copy], 1u);
+    atomicAdd(&s_hist[(((x >> 16) & 255u) << 5) | copy], 1u);
+    atomicAdd(&s_hist[((x >> 24) << 5) | copy], 1u);
+}
+
+__global__ __launch_bounds__(kThreads) void hist_partial_kernel(const uint8_t* __restrict__ src, HistGeom g,
+                                                                uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t s_hist[256 * kCopies];
+    const unsigned tid = threadIdx.x, copy = tid & 31u;
+#pragma unroll
+    for (int i = 0; i < 256 * kCopies / kThreads; ++i) s_hist[i * kThreads + tid] = 0;
+    __syncthreads();
+
+    const unsigned img = blockIdx.y;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    for (unsigned u = blockIdx.x; u < g.units_per_img; u += gridDim.x) {
+        const unsigned row = u / g.units_per_row;
+        const int64_t col0 = (int64_t)(u - row * g.units_per_row) * kUnit + (int64_t)tid * 16;
+        const uint8_t* sp = simg + (int64_t)row * g.s_row;
+        u32x4 v[kUnroll];
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            const int64_t c = col0 + (int64_t)j * kChunk;
+            if (c + 16 <= g.len) v[j] = ld16(sp + c);
+        }
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            const int64_t c = col0 + (int64_t)j * kChunk;
+            if (c + 16 <= g.len) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) count4(s_hist, v[j][k], copy);
+            } else if (c < g.len) {
+                for (int64_t b = c; b < g.len; ++b) atomicAdd(&s_hist[((uint32_t)sp[b] << 5) | copy], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // fold the 32 copies of bin `tid`; lane reads copy (j + tid) % 32 -> bank (j + tid) % 32: conflict-free
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kCopies; ++j) sum += s_hist[(tid << 5) | ((j + tid) & 31u)];
+    partial[((size_t)img * gridDim.x + blockIdx.x) * 256 + tid] = sum;
+}
+
+// One block per image: hist[bin] = sum over that image's partial blocks; optional equalization LUT.
+// OpenCV histogram.cpp equalizeHist(): i0 = first non-zero bin; hist[i0]==total -> constant image maps to i0;
+// scale = 255.f/(total-hist[i0]); lut[i0]=0; lut[i>i0] = saturate_cast<uchar>(cvRound(float(sum_i)*scale)).
+__global__ __launch_bounds__(kThreads) void hist_finish_kernel(const uint32_t* __restrict__ partial, unsigned nparts,
+                                                               const uint32_t* __restrict__ hist_in,
+                                                               uint32_t* __restrict__ hist_out,
+                                                               uint8_t* __restrict__ lut_out)
+{
+    __shared__ uint32_t s_scan[2][256];
+    __shared__ int s_i0;
+    const unsigned tid = threadIdx.x, img = blockIdx.x;
+    uint32_t h = 0;
+    if (partial) {
+        const uint32_t* p = partial + (size_t)img * nparts * 256 + tid;
+        unsigned b = 0;
+        for (; b + 8 <= nparts; b += 8) {
+            uint32_t t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = p[(size_t)(b + k) * 256];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) h += t[k];
+        }
+        for (; b < nparts; ++b) h += p[(size_t)b * 256];
+    } else {
+        h = hist_in[(size_t)img * 256 + tid];
+    }
+    if (hist_out) hist_out[(size_t)img * 256 + tid] = h;
+    if (!lut_out) return;
+
+    if (tid == 0) s_i0 = 256;
+    s_scan[0][tid] = h;
+    __syncthreads();
+    if (h != 0) atomicMin(&s_i0, (int)tid);
+    int cur = 0;                                             // Hillis-Steele inclusive scan over 256 bins
+#pragma unroll
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = s_scan[cur][tid];
+        if (tid >= (unsigned)off) v += s_scan[cur][tid - off];
+        s_scan[cur ^ 1][tid] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    const uint32_t incl = s_scan[cur][tid];                  // sum of bins 0..tid
+    const uint32_t total = s_scan[cur][255];
+    const int i0 = s_i0;
+    uint32_t out = 0;
+    // The raw counts were overwritten by the scan; hist[i0] == incl(i0) because every bin below i0 is empty.
+    if (i0 < 256) {
+        const uint32_t hist_i0 = s_scan[cur][i0];
+        if (hist_i0 == total) {
+            out = (uint32_t)i0;                              // single-valued image: dst.setTo(i0)
+        } else if ((int)tid > i0) {
+            const float scale = __fdiv_rn(255.f, (float)(int)(total - hist_i0));
+            const float v = __builtin_rintf(__fmul_rn((float)(int)(incl - hist_i0), scale));
+            out = v < 0.f ? 0u : v > 255.f ? 255u : (uint32_t)v;
+        }
+    }
+    lut_out[(size_t)img * 256 + tid] = (uint8_t)out;
+}
+
+HistGeom make_geom(int h, int w, int64_t s_row, int64_t s_img)
+{
+    HistGeom g;
+    g.rows = h; g.len = w; g.s_row = s_row; g.s_img = s_img;
+    if (s_row == w) { g.rows = 1; g.len = (int64_t)w * h; }
+    g.units_per_row = ipx_div_up((uint64_t)g.len, kUnit);
+    g.units_per_img = (unsigned)g.rows * g.units_per_row;
+    return g;
+}
+
+// blocks per image: enough blocks to fill the chip (LDS admits 4-5 blocks per CU), but at least
+// 64 KiB of pixels per block so that zeroing/folding the 32 KiB LDS histogram stays in the noise.
+unsigned blocks_per_image(int n, int h, int w)
+{
+    const uint64_t bytes = (uint64_t)h * (uint64_t)w;
+    uint64_t by_work = (bytes + 65535) / 65536;
+    uint64_t by_chip = (1280 + (uint64_t)n - 1) / (uint64_t)n;
+    uint64_t b = by_work < by_chip ? by_work : by_chip;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Workspace {
+    uint32_t* partial; uint32_t* hist; uint8_t* lut;
+};
+
+size_t workspace_layout(int n, int h, int w, Workspace* ws, uint8_t* base)
+{
+    const size_t p = align256((size_t)n * blocks_per_image(n, h, w) * 256 * sizeof(uint32_t));
+    const size_t hs = align256((size_t)n * 256 * sizeof(uint32_t));
+    const size_t ls = align256((size_t)n * 256);
+    if (ws) { ws->partial = (uint32_t*)base; ws->hist = (uint32_t*)(base + p); ws->lut = base + p + hs; }
+    return p + hs + ls;
+}
+
+int check_hist_args(const char* fn, const uint8_t* src, int n, int h, int w, int64_t s_row, int64_t s_img)
+{
+    if (int rc = ipx_check_image_args(fn, src, src, n, h, w, 1, 1, s_row, s_img, s_row, s_img)) return rc;
+    if ((uint64_t)h * (uint64_t)w > 0x7fffffffull)
+        return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: %d x %d pixels exceed int32 counts (OpenCV's own limit)", fn, h, w);
+    if (n > 65535) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: n=%d > 65535 images per call", fn, n);
+    return IPX_OK;
+}
+
+int launch_partial(hipStream_t st, const uint8_t* src, int n, int h, int w, int64_t s_row, int64_t s_img,
+                   uint32_t* partial, unsigned* nparts)
+{
+    HistGeom g = make_geom(h, w, s_row, s_img);
+    unsigned bpi = blocks_per_image(n, h, w);
+    if (bpi > g.units_per_img) bpi = g.units_per_img;     // strided rows: fewer units than bytes/64K suggests
+    *nparts = bpi;
+    hipLaunchKernelGGL(hist_partial_kernel, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, partial);
+    IPX_LAUNCH_CHECK("hist_partial_kernel");
+    return IPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ipx_hist_workspace_bytes(int n, int h, int w)
+{
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    return workspace_layout(n, h, w, nullptr, nullptr);
+}
+
+int ipx_hist_u8(void* stream, const uint8_t* src, int n, int h, int w, int64_t src_row_stride, int64_t src_img_stride,
+                uint32_t* hist_dev, void* workspace, size_t workspace_bytes)
+{
+    if (int rc = check_hist_args("ipx_hist_u8", src, n, h, w, src_row_stride, src_img_stride)) return rc;
+    if (!hist_dev) return ipx_fail(IPX_ERR_INVALID, "ipx_hist_u8: null histogram output");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = workspace_layout(n, h, w, nullptr, nullptr);
+    void* own = nullptr;
+    if (!workspace) {
+        IPX_HIP(hipMallocAsync(&own, need, st));
+        workspace = own;
+    } else if (workspace_bytes < need) {
+        return ipx_fail(IPX_ERR_INVALID, "ipx_hist_u8: workspace %zu < %zu bytes needed", workspace_bytes, need);
+    }
+    Workspace ws;
+    workspace_layout(n, h, w, &ws, (uint8_t*)workspace);
+    unsigned nparts = 0;
+    int rc = launch_partial(st, src, n, h, w, src_row_stride, src_img_stride, ws.partial, &nparts);
+    if (rc == IPX_OK) {
+        hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(kThreads), 0, st, ws.partial, nparts,
+                           (const uint32_t*)nullptr, hist_dev, (uint8_t*)nullptr);
+        if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "launch of hist_finish_kernel failed");
+    }
+    if (own) {
+        hipError_t e = hipFreeAsync(own, st);
+        if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
+    }
+    return rc;
+}
+
+int ipx_equalize_lut_u8(void* stream, const uint32_t* hist_dev, int n, uint8_t* lut_dev)
+{
+    ipx_clear_error();
+    if (!hist_dev || !lut_dev) return ipx_fail(IPX_ERR_INVALID, "ipx_equalize_lut_u8: null pointer");
+    if (n <= 0) return ipx_fail(IPX_ERR_INVALID, "ipx_equalize_lut_u8: n=%d must be positive", n);
+    hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const uint32_t*)nullptr, 0u, hist_dev, (uint32_t*)nullptr, lut_dev);
+    IPX_LAUNCH_CHECK("hist_finish_kernel");
+    return IPX_OK;
+}
+
+int ipx_equalize_hist_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                         int64_t src_row_stride, int64_t src_img_stride, int64_t dst_row_stride, int64_t dst_img_stride,
+                         uint32_t* hist_out_dev, uint8_t* lut_out_dev, void* workspace, size_t workspace_bytes)
+{
+    if (int rc = ipx_check_image_args("ipx_equalize_hist_u8", src, dst, n, h, w, 1, 1, src_row_stride, src_img_stride,
+                                      dst_row_stride, dst_img_stride)) return rc;
+    if (int rc = check_hist_args("ipx_equalize_hist_u8", src, n, h, w, src_row_stride, src_img_stride)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = workspace_layout(n, h, w, nullptr, nullptr);
+    void* own = nullptr;
+    if (!workspace) {
+        IPX_HIP(hipMallocAsync(&own, need, st));
+        workspace = own;
+    } else if (workspace_bytes < need) {
+        return ipx_fail(IPX_ERR_INVALID, "ipx_equalize_hist_u8: workspace %zu < %zu bytes needed", workspace_bytes, need);
+    }
+    Workspace ws;
+    workspace_layout(n, h, w, &ws, (uint8_t*)workspace);
+    uint8_t* lut = lut_out_dev ? lut_out_dev : ws.lut;
+    unsigned nparts = 0;
+    int rc = launch_partial(st, src, n, h, w, src_row_stride, src_img_stride, ws.partial, &nparts);
+    if (rc == IPX_OK) {
+        hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(kThreads), 0, st, ws.partial, nparts,
+                           (const uint32_t*)nullptr, hist_out_dev, lut);
+        if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "launch of hist_finish_kernel failed");
+    }
+    if (rc == IPX_OK)
+        rc = ipx_lut_dev_u8(stream, src, dst, n, h, w, 1, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride,
+                            lut, 256);
+    if (own) {
+        hipError_t e = hipFreeAsync(own, st);
+        if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
+    }
+    return rc;
+}
+
+}  // extern "C"

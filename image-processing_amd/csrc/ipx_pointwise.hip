@@ -1,0 +1,285 @@
+// ipx_pointwise.hip -- pixel-wise kernels: 256-entry LUT application, BGR(A)->gray, fused gray+LUT.
+//
+// All are pure HBM streams (LUT: 2 B/px, gray: 4 B/px for 3 channels).  Each lane moves 16 output bytes
+// per step with 16-byte global loads/stores; a block walks "units" of UNROLL x 4 KiB so that UNROLL
+// independent loads are in flight per lane.  The table lives in LDS (256 B) and is read with ds_read_u8.
+#include "ipx_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 4;
+constexpr int kChunk = kThreads * 16;           // bytes (or pixels) one block-wide step covers
+constexpr int kUnit = kChunk * kUnroll;
+
+struct LutArg { uint32_t w[64]; };              // 256-byte table passed by value in the kernarg segment
+
+struct PwGeom {
+    int rows;                // rows per image after collapsing contiguous images into one long row
+    int64_t len;             // OUTPUT elements per row (bytes for LUT, pixels for gray)
+    int64_t s_row, s_img, d_row, d_img;
+    unsigned units_per_row;  // ceil(len / kUnit)
+    unsigned units_per_img;  // rows * units_per_row
+};
+
+__device__ __forceinline__ uint32_t lut4(const uint8_t* sl, uint32_t x)
+{
+    return (uint32_t)sl[x & 255u] | ((uint32_t)sl[(x >> 8) & 255u] << 8) |
+           ((uint32_t)sl[(x >> 16) & 255u] << 16) | ((uint32_t)sl[x >> 24] << 24);
+}
+
+__device__ __forceinline__ void load_lut(uint32_t* s_lut, const LutArg& lutv, const uint8_t* lut_dev, bool byval)
+{
+    if (threadIdx.x < 64) {
+        uint32_t v;
+        if (byval) v = lutv.w[threadIdx.x];
+        else __builtin_memcpy(&v, lut_dev + 4 * threadIdx.x, 4);
+        s_lut[threadIdx.x] = v;
+    }
+    __syncthreads();
+}
+
+// dst = lut[src]; blockIdx.y = image, blockIdx.x grid-strides over the image's units.
+template <bool BYVAL>
+__global__ __launch_bounds__(kThreads) void lut_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                       PwGeom g, LutArg lutv, const uint8_t* __restrict__ lut_dev,
+                                                       int64_t lut_stride)
+{
+    __shared__ uint32_t s_lut[64];
+    const unsigned img = blockIdx.y;
+    load_lut(s_lut, lutv, BYVAL ? nullptr : lut_dev + (int64_t)img * lut_stride, BYVAL);
+    const uint8_t* sl = reinterpret_cast<const uint8_t*>(s_lut);
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+
+    for (unsigned u = blockIdx.x; u < g.units_per_img; u += gridDim.x) {
+        const unsigned row = u / g.units_per_row;
+        const int64_t col0 = (int64_t)(u - row * g.units_per_row) * kUnit + (int64_t)threadIdx.x * 16;
+        const uint8_t* sp = simg + (int64_t)row * g.s_row;
+        uint8_t* dp = dimg + (int64_t)row * g.d_row;
+        u32x4 v[kUnroll];
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            const int64_t c = col0 + (int64_t)j * kChunk;
+            if (c + 16 <= g.len) v[j] = ld16(sp + c);
+        }
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            const int64_t c = col0 + (int64_t)j * kChunk;
+            if (c + 16 <= g.len) {
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = lut4(sl, v[j][k]);
+                st16(dp + c, o);
+            } else if (c < g.len) {                      // ragged tail of the row: byte by byte
+                for (int64_t b = c; b < g.len; ++b) dp[b] = sl[sp[b]];
+            }
+        }
+    }
+}
+
+// gray = (3735 B + 19235 G + 9798 R + 16384) >> 15   (OpenCV RGB2Gray<uchar>, Q15)
+__device__ __forceinline__ uint32_t gray_q15(uint32_t b, uint32_t g, uint32_t r)
+{
+    return (3735u * b + 19235u * g + 9798u * r + 16384u) >> 15;
+}
+
+template <int C> struct PxVec;                                   // 16 pixels of C interleaved bytes
+template <> struct PxVec<3> { u32x4 q[3]; };
+template <> struct PxVec<4> { u32x4 q[4]; };
+
+template <int C>
+__device__ __forceinline__ void load_px16(PxVec<C>& p, const uint8_t* s)
+{
+#pragma unroll
+    for (int i = 0; i < C; ++i) p.q[i] = ld16(s + 16 * i);
+}
+
+template <int C>
+__device__ __forceinline__ uint32_t px_byte(const PxVec<C>& p, int byte_index)   // static after unrolling
+{
+    return (p.q[byte_index >> 4][(byte_index >> 2) & 3] >> (8 * (byte_index & 3))) & 255u;
+}
+
+// dst = gray(src) or lut[gray(src)]; lane = 16 pixels (48 or 64 source bytes -> 16 output bytes)
+template <int C, bool WITH_LUT>
+__global__ __launch_bounds__(kThreads) void gray_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                        PwGeom g, LutArg lutv)
+{
+    __shared__ uint32_t s_lut[64];
+    if (WITH_LUT) load_lut(s_lut, lutv, nullptr, true);
+    const uint8_t* sl = reinterpret_cast<const uint8_t*>(s_lut);
+    const unsigned img = blockIdx.y;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    constexpr int U = 2;                                  // 2 x (3|4) x 16 B loads in flight per lane
+
+    for (unsigned u = blockIdx.x; u < g.units_per_img; u += gridDim.x) {
+        const unsigned row = u / g.units_per_row;
+        const int64_t px0 = (int64_t)(u - row * g.units_per_row) * (kChunk * U) + (int64_t)threadIdx.x * 16;
+        const uint8_t* sp = simg + (int64_t)row * g.s_row;
+        uint8_t* dp = dimg + (int64_t)row * g.d_row;
+        PxVec<C> p[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int64_t x = px0 + (int64_t)j * kChunk;
+            if (x + 16 <= g.len) load_px16<C>(p[j], sp + x * C);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int64_t x = px0 + (int64_t)j * kChunk;
+            if (x + 16 <= g.len) {
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int px = 4 * k + i;
+                        uint32_t y = gray_q15(px_byte<C>(p[j], px * C), px_byte<C>(p[j], px * C + 1), px_byte<C>(p[j], px * C + 2));
+                        if (WITH_LUT) y = sl[y];
+                        word |= y << (8 * i);
+                    }
+                    o[k] = word;
+                }
+                st16(dp + x, o);
+            } else if (x < g.len) {
+                for (int64_t q = x; q < g.len; ++q) {
+                    const uint8_t* s = sp + q * C;
+                    uint32_t y = gray_q15(s[0], s[1], s[2]);
+                    if (WITH_LUT) y = sl[y];
+                    dp[q] = (uint8_t)y;
+                }
+            }
+        }
+    }
+}
+
+// len_in_row: output elements per row; in_bpe: source bytes per output element
+PwGeom make_geom(int h, int64_t len_in_row, int in_bpe, int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
+                 int unit)
+{
+    PwGeom g;
+    g.rows = h; g.len = len_in_row;
+    g.s_row = s_row; g.s_img = s_img; g.d_row = d_row; g.d_img = d_img;
+    if (s_row == len_in_row * in_bpe && d_row == len_in_row) {   // contiguous image: one long row
+        g.rows = 1; g.len = len_in_row * (int64_t)h;
+    }
+    g.units_per_row = ipx_div_up((uint64_t)g.len, (uint64_t)unit);
+    g.units_per_img = (unsigned)g.rows * g.units_per_row;
+    return g;
+}
+
+dim3 make_grid(const PwGeom& g, int n)
+{
+    // memory-bound streaming: ~16 blocks per CU in total is plenty; grid-stride over the rest
+    unsigned per_img = g.units_per_img;
+    unsigned cap = (unsigned)(4096 / (n < 4096 ? n : 4096));
+    if (cap < 1) cap = 1;
+    if (per_img > cap) per_img = cap;
+    return dim3(per_img, (unsigned)n, 1);
+}
+
+int check_units(const char* fn, const PwGeom& g, int h, int64_t len, int unit)
+{
+    const uint64_t upr = ((uint64_t)g.len + unit - 1) / unit;
+    if (upr * (uint64_t)g.rows > 0xffffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: image too large", fn);
+    (void)h; (void)len;
+    return IPX_OK;
+}
+
+int launch_lut(const char* fn, void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+               int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
+               const uint8_t* lut_host, const uint8_t* lut_dev, int64_t lut_stride)
+{
+    if (int rc = ipx_check_image_args(fn, src, dst, n, h, w, c, c, s_row, s_img, d_row, d_img)) return rc;
+    PwGeom g = make_geom(h, (int64_t)w * c, 1, s_row, s_img, d_row, d_img, kUnit);
+    if (int rc = check_units(fn, g, h, (int64_t)w * c, kUnit)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    LutArg la{};
+    if (lut_host) __builtin_memcpy(la.w, lut_host, 256);
+    for (int i0 = 0; i0 < n; i0 += 65535) {
+        const int nb = n - i0 < 65535 ? n - i0 : 65535;
+        const uint8_t* s = src + (int64_t)i0 * s_img;
+        uint8_t* d = dst + (int64_t)i0 * d_img;
+        dim3 grid = make_grid(g, nb);
+        if (lut_host)
+            hipLaunchKernelGGL(lut_kernel<true>, grid, dim3(kThreads), 0, st, s, d, g, la, (const uint8_t*)nullptr, (int64_t)0);
+        else
+            hipLaunchKernelGGL(lut_kernel<false>, grid, dim3(kThreads), 0, st, s, d, g, la, lut_dev + (int64_t)i0 * lut_stride, lut_stride);
+        IPX_LAUNCH_CHECK("lut_kernel");
+    }
+    return IPX_OK;
+}
+
+int launch_gray(const char* fn, void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int sc,
+                int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* lut_host)
+{
+    if (sc != 3 && sc != 4) {
+        ipx_clear_error();
+        return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: src_channels=%d (3 = BGR or 4 = BGRA expected)", fn, sc);
+    }
+    if (int rc = ipx_check_image_args(fn, src, dst, n, h, w, sc, 1, s_row, s_img, d_row, d_img)) return rc;
+    constexpr int unit = kChunk * 2;
+    PwGeom g = make_geom(h, (int64_t)w, sc, s_row, s_img, d_row, d_img, unit);
+    if (int rc = check_units(fn, g, h, w, unit)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    LutArg la{};
+    if (lut_host) __builtin_memcpy(la.w, lut_host, 256);
+    for (int i0 = 0; i0 < n; i0 += 65535) {
+        const int nb = n - i0 < 65535 ? n - i0 : 65535;
+        const uint8_t* s = src + (int64_t)i0 * s_img;
+        uint8_t* d = dst + (int64_t)i0 * d_img;
+        dim3 grid = make_grid(g, nb);
+        if (sc == 3) {
+            if (lut_host) hipLaunchKernelGGL((gray_kernel<3, true>), grid, dim3(kThreads), 0, st, s, d, g, la);
+            else hipLaunchKernelGGL((gray_kernel<3, false>), grid, dim3(kThreads), 0, st, s, d, g, la);
+        } else {
+            if (lut_host) hipLaunchKernelGGL((gray_kernel<4, true>), grid, dim3(kThreads), 0, st, s, d, g, la);
+            else hipLaunchKernelGGL((gray_kernel<4, false>), grid, dim3(kThreads), 0, st, s, d, g, la);
+        }
+        IPX_LAUNCH_CHECK("gray_kernel");
+    }
+    return IPX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ipx_lut_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+               int64_t src_row_stride, int64_t src_img_stride, int64_t dst_row_stride, int64_t dst_img_stride,
+               const uint8_t* lut_host)
+{
+    if (!lut_host) { ipx_clear_error(); return ipx_fail(IPX_ERR_INVALID, "ipx_lut_u8: null table"); }
+    return launch_lut("ipx_lut_u8", stream, src, dst, n, h, w, c, src_row_stride, src_img_stride,
+                      dst_row_stride, dst_img_stride, lut_host, nullptr, 0);
+}
+
+int ipx_lut_dev_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+                   int64_t src_row_stride, int64_t src_img_stride, int64_t dst_row_stride, int64_t dst_img_stride,
+                   const uint8_t* lut_dev, int64_t lut_stride)
+{
+    if (!lut_dev) { ipx_clear_error(); return ipx_fail(IPX_ERR_INVALID, "ipx_lut_dev_u8: null table"); }
+    if (lut_stride != 0 && lut_stride < 256) { ipx_clear_error(); return ipx_fail(IPX_ERR_INVALID, "ipx_lut_dev_u8: lut_stride %lld must be 0 or >= 256", (long long)lut_stride); }
+    return launch_lut("ipx_lut_dev_u8", stream, src, dst, n, h, w, c, src_row_stride, src_img_stride,
+                      dst_row_stride, dst_img_stride, nullptr, lut_dev, lut_stride);
+}
+
+int ipx_bgr2gray_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int src_channels,
+                    int64_t src_row_stride, int64_t src_img_stride, int64_t dst_row_stride, int64_t dst_img_stride)
+{
+    return launch_gray("ipx_bgr2gray_u8", stream, src, dst, n, h, w, src_channels, src_row_stride, src_img_stride,
+                       dst_row_stride, dst_img_stride, nullptr);
+}
+
+int ipx_bgr2gray_lut_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int src_channels,
+                        int64_t src_row_stride, int64_t src_img_stride, int64_t dst_row_stride, int64_t dst_img_stride,
+                        const uint8_t* lut_host)
+{
+    if (!lut_host) { ipx_clear_error(); return ipx_fail(IPX_ERR_INVALID, "ipx_bgr2gray_lut_u8: null table"); }
+    return launch_gray("ipx_bgr2gray_lut_u8", stream, src, dst, n, h, w, src_channels, src_row_stride, src_img_stride,
+                       dst_row_stride, dst_img_stride, lut_host);
+}
+
+}  // extern "C"

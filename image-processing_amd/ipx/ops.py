@@ -1,0 +1,251 @@
+"""Tensor-level operators over libipx (PyTorch-ROCm is plumbing: device memory + streams).
+
+Every function takes uint8 CUDA tensors laid out like the reference's numpy arrays
+(`H x W`, `H x W x C`) or a batch of them (`N x H x W x C`; a gray batch is `N x H x W x 1`),
+launches on `torch.cuda.current_stream()` and returns a new tensor.  Names follow the reference
+call sites they replace (server.py).  No CPU fallback: a CPU tensor is an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class _Img:
+    """(n, h, w, c, row_stride, img_stride, ptr) view of a tensor; inner (w, c) must be dense."""
+
+    def __init__(self, t: torch.Tensor, name: str = "src"):
+        if not isinstance(t, torch.Tensor) or t.dtype != torch.uint8:
+            raise TypeError(f"{name}: uint8 torch tensor expected")
+        if not t.is_cuda:
+            raise RuntimeError(f"{name}: tensor is on {t.device}; libipx runs on the GPU only (no CPU fallback)")
+        if t.ndim == 2:
+            v = t[None, :, :, None]
+        elif t.ndim == 3:
+            if t.shape[2] > 4:
+                raise ValueError(f"{name}: 3-D tensor is read as H x W x C with C <= 4; use N x H x W x 1 for a gray batch")
+            v = t[None]
+        elif t.ndim == 4:
+            v = t
+        else:
+            raise ValueError(f"{name}: expected 2-D, 3-D or 4-D tensor, got {t.ndim}-D")
+        n, h, w, c = v.shape
+        if n == 0 or h == 0 or w == 0:
+            raise ValueError(f"{name}: empty image {tuple(t.shape)}")
+        if c > 4:
+            raise ValueError(f"{name}: {c} channels (at most 4 interleaved channels)")
+        if (c > 1 and v.stride(3) != 1) or (w > 1 and v.stride(2) != c):
+            v = v.contiguous()
+        self.t = v
+        self.n, self.h, self.w, self.c = n, h, w, c
+        self.row = v.stride(1) if h > 1 else w * c
+        self.img = v.stride(0) if n > 1 else max(self.row * h, 1)
+        if self.row < w * c or (n > 1 and self.img < self.row * (h - 1) + w * c):
+            self.t = v = v.contiguous()
+            self.row, self.img = w * c, w * c * h
+        self.ptr = v.data_ptr()
+        self.ndim_in = t.ndim
+
+    def like(self, c: Optional[int] = None) -> torch.Tensor:
+        return torch.empty((self.n, self.h, self.w, self.c if c is None else c), dtype=torch.uint8, device=self.t.device)
+
+    def restore(self, out: torch.Tensor) -> torch.Tensor:
+        if self.ndim_in == 2:
+            return out[0, :, :, 0]
+        if self.ndim_in == 3:
+            return out[0]
+        return out
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _lut_np(lut) -> np.ndarray:
+    a = np.ascontiguousarray(np.asarray(lut), dtype=np.uint8)
+    if a.shape != (256,):
+        raise ValueError("table must have 256 uint8 entries")
+    return a
+
+
+def _halo(t: Optional[torch.Tensor], src: _Img, r: int, name: str):
+    if t is None:
+        return None, None
+    if src.n != 1:
+        raise ValueError("halo rows are only defined for a single image")
+    hv = _Img(t, name)
+    if hv.h != r or hv.w != src.w or hv.c != src.c:
+        raise ValueError(f"{name}: expected {r} x {src.w} x {src.c}, got {hv.h} x {hv.w} x {hv.c}")
+    if hv.h > 1 and hv.row != src.row:
+        hv = _Img(t.contiguous(), name)
+        if hv.row != src.row:
+            raise ValueError(f"{name}: row stride {hv.row} differs from the image's {src.row}")
+    return hv, hv.ptr
+
+
+# ---- pixel-wise ----------------------------------------------------------------------------------
+def bgr2gray(src: torch.Tensor) -> torch.Tensor:
+    """cv2.cvtColor(img, COLOR_BGR2GRAY) (server.py:517); a 4th channel is dropped (server.py:511)."""
+    s = _Img(src)
+    if s.c not in (3, 4):
+        raise ValueError("bgr2gray needs 3 (BGR) or 4 (BGRA) channels")
+    with torch.cuda.device(s.t.device):
+        out = s.like(1)
+        _lib.call("ipx_bgr2gray_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w, s.c,
+                  s.row, s.img, s.w, s.w * s.h)
+    return out[0, :, :, 0] if src.ndim == 3 else out
+
+
+def apply_lut(src: torch.Tensor, lut) -> torch.Tensor:
+    """dst = lut[src] with one 256-entry host table (negative/threshold/gamma/log/piecewise, server.py:362-388,443-467)."""
+    s = _Img(src)
+    tab = _lut_np(lut)
+    with torch.cuda.device(s.t.device):
+        out = s.like()
+        _lib.call("ipx_lut_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w, s.c,
+                  s.row, s.img, s.w * s.c, s.w * s.c * s.h, tab.ctypes.data)
+    return s.restore(out)
+
+
+def apply_lut_dev(src: torch.Tensor, luts: torch.Tensor) -> torch.Tensor:
+    """Per-image device tables: luts is (256,) shared or (N, 256)."""
+    s = _Img(src)
+    if luts.dtype != torch.uint8 or not luts.is_cuda or luts.shape[-1] != 256:
+        raise ValueError("luts: uint8 CUDA tensor of shape (256,) or (N, 256) expected")
+    luts = luts.contiguous()
+    stride = 0 if luts.ndim == 1 else 256
+    if luts.ndim == 2 and luts.shape[0] != s.n:
+        raise ValueError("one table per image expected")
+    with torch.cuda.device(s.t.device):
+        out = s.like()
+        _lib.call("ipx_lut_dev_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w, s.c,
+                  s.row, s.img, s.w * s.c, s.w * s.c * s.h, luts.data_ptr(), stride)
+    return s.restore(out)
+
+
+def bgr2gray_lut(src: torch.Tensor, lut) -> torch.Tensor:
+    """Fused cvtColor(BGR2GRAY) + table (one 4 B/px pass instead of 4 + 2)."""
+    s = _Img(src)
+    if s.c not in (3, 4):
+        raise ValueError("bgr2gray_lut needs 3 (BGR) or 4 (BGRA) channels")
+    tab = _lut_np(lut)
+    with torch.cuda.device(s.t.device):
+        out = s.like(1)
+        _lib.call("ipx_bgr2gray_lut_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w, s.c,
+                  s.row, s.img, s.w, s.w * s.h, tab.ctypes.data)
+    return out[0, :, :, 0] if src.ndim == 3 else out
+
+
+# ---- histogram -----------------------------------------------------------------------------------
+def _gray(src: torch.Tensor) -> _Img:
+    s = _Img(src)
+    if s.c != 1:
+        raise ValueError("single-channel (gray) image expected")
+    return s
+
+
+def hist(src: torch.Tensor) -> torch.Tensor:
+    """256-bin histogram per image -> int32 tensor (N, 256) (or (256,) for a single H x W image).
+    Counts are uint32 in the library; exposed as int32 because image sizes are capped at 2^31-1 pixels."""
+    s = _gray(src)
+    with torch.cuda.device(s.t.device):
+        out = torch.empty((s.n, 256), dtype=torch.int32, device=s.t.device)
+        _lib.call("ipx_hist_u8", _stream(), s.ptr, s.n, s.h, s.w, s.row, s.img, out.data_ptr(), None, 0)
+    return out[0] if src.ndim <= 3 else out
+
+
+def equalize_lut(hists: torch.Tensor) -> torch.Tensor:
+    """cv2.equalizeHist's table from histograms (N,256) int32 -> (N,256) uint8."""
+    if hists.dtype != torch.int32 or not hists.is_cuda or hists.shape[-1] != 256:
+        raise ValueError("hists: int32 CUDA tensor (..., 256) expected")
+    h2 = hists.reshape(-1, 256).contiguous()
+    with torch.cuda.device(h2.device):
+        out = torch.empty((h2.shape[0], 256), dtype=torch.uint8, device=h2.device)
+        _lib.call("ipx_equalize_lut_u8", _stream(), h2.data_ptr(), h2.shape[0], out.data_ptr())
+    return out.reshape(hists.shape)
+
+
+def equalize_hist(src: torch.Tensor, return_aux: bool = False):
+    """cv2.equalizeHist(img) (server.py:246)."""
+    s = _gray(src)
+    with torch.cuda.device(s.t.device):
+        out = s.like()
+        hst = lut = None
+        if return_aux:
+            hst = torch.empty((s.n, 256), dtype=torch.int32, device=s.t.device)
+            lut = torch.empty((s.n, 256), dtype=torch.uint8, device=s.t.device)
+        _lib.call("ipx_equalize_hist_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w,
+                  s.row, s.img, s.w, s.w * s.h,
+                  hst.data_ptr() if return_aux else None, lut.data_ptr() if return_aux else None, None, 0)
+    res = s.restore(out)
+    return (res, hst, lut) if return_aux else res
+
+
+# ---- convolutions --------------------------------------------------------------------------------
+def _conv3(name: str, src: torch.Tensor, top: Optional[torch.Tensor], bottom: Optional[torch.Tensor]) -> torch.Tensor:
+    s = _Img(src)
+    tv, tp = _halo(top, s, 1, "top_halo")
+    bv, bp = _halo(bottom, s, 1, "bottom_halo")
+    with torch.cuda.device(s.t.device):
+        out = s.like()
+        _lib.call(name, _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w, s.c,
+                  s.row, s.img, s.w * s.c, s.w * s.c * s.h, tp, bp)
+    return s.restore(out)
+
+
+def laplacian_sharpen(src, top_halo=None, bottom_halo=None):
+    """clip(f64(c) - cv2.Laplacian(c, CV_64F), 0, 255) per channel (server.py:266-276)."""
+    return _conv3("ipx_laplacian_sharpen_u8", src, top_halo, bottom_halo)
+
+
+def box3(src, top_halo=None, bottom_halo=None):
+    """3x3 normalised box blur (BASELINE.json configs[0]; not in the reference)."""
+    return _conv3("ipx_box3_u8", src, top_halo, bottom_halo)
+
+
+def sobel(src, top_halo=None, bottom_halo=None):
+    """min(255, |gx| + |gy|) (BASELINE.json configs[1]; not in the reference)."""
+    return _conv3("ipx_sobel_u8", src, top_halo, bottom_halo)
+
+
+def gauss_kernel_q8(k: int, sigma: float = 0.0) -> np.ndarray:
+    """Q0.8 taps cv2.GaussianBlur uses on uint8 (library helper, host side)."""
+    if k < 1 or k % 2 == 0 or k > _lib.MAX_GAUSS_K:
+        raise ValueError(f"k={k} must be odd and in 1..{_lib.MAX_GAUSS_K}")
+    out = np.zeros(k, np.uint16)
+    _lib.call("ipx_gauss_kernel_q8", int(k), C.c_double(sigma), out.ctypes.data)
+    return out
+
+
+def sep_filter_q8(src, kx: Sequence[int], ky: Sequence[int], top_halo=None, bottom_halo=None) -> torch.Tensor:
+    s = _Img(src)
+    kx = np.ascontiguousarray(kx, np.uint16)
+    ky = np.ascontiguousarray(ky, np.uint16)
+    if kx.shape != ky.shape or kx.ndim != 1:
+        raise ValueError("kx and ky must have the same odd length")
+    r = len(kx) // 2
+    tv, tp = _halo(top_halo, s, r, "top_halo") if r else (None, None)
+    bv, bp = _halo(bottom_halo, s, r, "bottom_halo") if r else (None, None)
+    with torch.cuda.device(s.t.device):
+        out = s.like()
+        _lib.call("ipx_sep_filter_q8_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w, s.c,
+                  s.row, s.img, s.w * s.c, s.w * s.c * s.h, kx.ctypes.data, ky.ctypes.data, len(kx), tp, bp)
+    return s.restore(out)
+
+
+def gaussian_blur(src, k: int, top_halo=None, bottom_halo=None) -> torch.Tensor:
+    """cv2.GaussianBlur(img, (k, k), 0) on uint8 (server.py:428)."""
+    s = _Img(src)
+    r = k // 2
+    tv, tp = _halo(top_halo, s, r, "top_halo") if r else (None, None)
+    bv, bp = _halo(bottom_halo, s, r, "bottom_halo") if r else (None, None)
+    with torch.cuda.device(s.t.device):
+        out = s.like()
+        _lib.call("ipx_gaussian_blur_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w, s.c,
+                  s.row, s.img, s.w * s.c, s.w * s.c * s.h, int(k), tp, bp)
+    return s.restore(out)

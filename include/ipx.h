@@ -1,0 +1,161 @@
+/* ipx.h -- C ABI of libipx.so, the MI355X (gfx950) kernel library behind the reference's
+ * /api/process image hot path (duyavaliable/image-processing, server.py).
+ *
+ * The reference has no FFI of its own: its "operator interface" for this path is the set of
+ * whole-array cv2 / numpy call sites inside api_process().  Each entry point below replaces one of
+ * those call sites (cited as server.py:LINE) and is what a ctypes binding in server.py would bind
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *  - Plain C, no exceptions cross the boundary.  Return 0 on success, a negative IPX_ERR_* code on
+ *    failure; ipx_last_error() returns the calling thread's last message.
+ *  - All image pointers are DEVICE pointers (hipMalloc / PyTorch-ROCm tensor.data_ptr()) on the
+ *    calling thread's current HIP device.  The caller owns every buffer; the library never frees
+ *    caller memory.  src and dst must not overlap unless an entry point says in-place is allowed.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is enqueued on
+ *    it; no entry point synchronises the device.  The library keeps no mutable global state, so
+ *    concurrent calls from different host threads (Flask workers, one thread per GPU) are safe as
+ *    long as they do not share output buffers.
+ *  - Images are uint8, C-contiguous inside a row, channels interleaved (BGR order where it matters),
+ *    as in the reference (H x W or H x W x 3 numpy arrays).  A batch is `n` images of identical
+ *    geometry; image i starts at base + i*img_stride bytes and row y at + y*row_stride bytes.
+ *    row_stride >= w*c; strides are in bytes.
+ *  - Borders are OpenCV's BORDER_DEFAULT (BORDER_REFLECT_101) everywhere, as in the reference.
+ *    Convolutions accept optional halo rows (`top_halo` / `bottom_halo`, `r` rows each with the
+ *    source row stride, NULL = reflect at the image edge) so that a row-partitioned giant image can be
+ *    filtered shard by shard after a halo exchange.
+ */
+#ifndef IPX_H
+#define IPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPX_OK 0
+#define IPX_ERR_INVALID (-1)     /* bad argument (null pointer, non-positive size, stride < row bytes ...) */
+#define IPX_ERR_HIP (-2)         /* a HIP runtime call failed; message holds hipGetErrorString */
+#define IPX_ERR_UNSUPPORTED (-3) /* valid request this build does not implement (e.g. channels > 4) */
+
+#define IPX_MAX_GAUSS_K 255      /* largest separable kernel size accepted by ipx_sep_filter_q8_u8 */
+
+/* library version (major*10000 + minor*100 + patch) */
+int ipx_version(void);
+/* thread-local message of the last failing call ("" if none) */
+const char* ipx_last_error(void);
+/* 0 if the current HIP device is a gfx950 (MI355X), IPX_ERR_UNSUPPORTED otherwise */
+int ipx_check_device(void);
+
+/* ---- pixel-wise --------------------------------------------------------------------------- */
+
+/* cv2.cvtColor(img, COLOR_BGR2GRAY) on uint8 -- server.py:517 (and :511 BGRA2BGR when src_channels==4:
+ * the alpha byte is dropped, not blended).  gray = (3735*B + 19235*G + 9798*R + 16384) >> 15.
+ * src: n x h x w x src_channels (3 or 4), dst: n x h x w. */
+int ipx_bgr2gray_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int src_channels,
+                    int64_t src_row_stride, int64_t src_img_stride,
+                    int64_t dst_row_stride, int64_t dst_img_stride);
+
+/* dst = lut[src] with one 256-entry table given in HOST memory (copied into the launch, the pointer
+ * may be reused as soon as the call returns).  Replaces the numpy pixel-wise expressions, each of
+ * which is a function of the pixel value alone: negative server.py:376, gamma :370-372, log :385-388
+ * (table depends on the image maximum), piecewise :459-467, and cv2.threshold :380.
+ * `c` is the interleaved channel count (the table is applied to every byte).  In-place (dst==src,
+ * same strides) is allowed. */
+int ipx_lut_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+               int64_t src_row_stride, int64_t src_img_stride,
+               int64_t dst_row_stride, int64_t dst_img_stride, const uint8_t* lut_host);
+
+/* Same with per-image tables in DEVICE memory: image i uses lut_dev + i*lut_stride (lut_stride 0 =
+ * one shared table).  Second half of cv2.equalizeHist, server.py:246.  In-place allowed. */
+int ipx_lut_dev_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+                   int64_t src_row_stride, int64_t src_img_stride,
+                   int64_t dst_row_stride, int64_t dst_img_stride,
+                   const uint8_t* lut_dev, int64_t lut_stride);
+
+/* Fused cvtColor(BGR2GRAY) + table: dst = lut[gray(src)] (server.py:360 followed by any of :362-388,
+ * :443-467 in one pass, 4 B/px instead of 4 + 2). */
+int ipx_bgr2gray_lut_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int src_channels,
+                        int64_t src_row_stride, int64_t src_img_stride,
+                        int64_t dst_row_stride, int64_t dst_img_stride, const uint8_t* lut_host);
+
+/* ---- histogram ---------------------------------------------------------------------------- */
+
+/* Scratch bytes ipx_hist_u8 / ipx_equalize_hist_u8 need for a batch of this geometry (device memory,
+ * 256-byte aligned, contents don't matter).  Pass such a buffer as `workspace`, or NULL to let the
+ * call take it from the stream-ordered allocator (hipMallocAsync/hipFreeAsync on `stream`). */
+size_t ipx_hist_workspace_bytes(int n, int h, int w);
+
+/* 256-bin histogram of each image: hist_dev[i*256 + v] = #pixels of image i equal to v (uint32).
+ * First half of cv2.equalizeHist (server.py:246); also the source of s.max() for the log transform
+ * (:387) and of the denoise_manual statistics (:193-200). */
+int ipx_hist_u8(void* stream, const uint8_t* src, int n, int h, int w,
+                int64_t src_row_stride, int64_t src_img_stride,
+                uint32_t* hist_dev, void* workspace, size_t workspace_bytes);
+
+/* LUT construction of cv2.equalizeHist from n histograms (device -> device): first non-zero bin i0,
+ * scale = 255.f/(total - hist[i0]) in float32, lut[i] = saturate_u8(rint(float(cumsum)*scale));
+ * a single-valued image maps to itself.  Separate so that a row-partitioned image can all-reduce
+ * its histogram between ipx_hist_u8 and this call. */
+int ipx_equalize_lut_u8(void* stream, const uint32_t* hist_dev, int n, uint8_t* lut_dev);
+
+/* cv2.equalizeHist(img) -- server.py:246.  hist_out_dev (n*256 uint32) and lut_out_dev (n*256 uint8)
+ * may be NULL; when given they receive the histogram and table that were used. */
+int ipx_equalize_hist_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                         int64_t src_row_stride, int64_t src_img_stride,
+                         int64_t dst_row_stride, int64_t dst_img_stride,
+                         uint32_t* hist_out_dev, uint8_t* lut_out_dev,
+                         void* workspace, size_t workspace_bytes);
+
+/* ---- 3x3 convolutions --------------------------------------------------------------------- */
+
+/* clip(f64(ch) - cv2.Laplacian(ch, CV_64F), 0, 255).astype(u8) per channel -- server.py:266-276,
+ * i.e. clip(5c - n - s - e - w, 0, 255) with REFLECT_101.  c = 1..4 interleaved channels. */
+int ipx_laplacian_sharpen_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+                             int64_t src_row_stride, int64_t src_img_stride,
+                             int64_t dst_row_stride, int64_t dst_img_stride,
+                             const uint8_t* top_halo, const uint8_t* bottom_halo);
+
+/* 3x3 normalised box blur, round-half-even(sum/9) (cv2.blur convention).  Named by BASELINE.json
+ * configs[0]; NOT present in the reference -- definition is this build's. */
+int ipx_box3_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+                int64_t src_row_stride, int64_t src_img_stride,
+                int64_t dst_row_stride, int64_t dst_img_stride,
+                const uint8_t* top_halo, const uint8_t* bottom_halo);
+
+/* Sobel magnitude min(255, |gx| + |gy|), gx = [-1 0 1; -2 0 2; -1 0 1], gy = gx^T.  Named by
+ * BASELINE.json configs[1]; NOT present in the reference -- definition is this build's. */
+int ipx_sobel_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+                 int64_t src_row_stride, int64_t src_img_stride,
+                 int64_t dst_row_stride, int64_t dst_img_stride,
+                 const uint8_t* top_halo, const uint8_t* bottom_halo);
+
+/* ---- separable Gaussian ------------------------------------------------------------------- */
+
+/* Host helper: the Q0.8 kernel cv2.GaussianBlur(img,(k,k),sigma) uses on uint8 input (fixed tables
+ * for sigma<=0 and k<=9, else sigma = 0.15k+0.35; error-diffused rounding, taps sum to 256).
+ * out holds k uint16.  k odd, 1 <= k <= IPX_MAX_GAUSS_K. */
+int ipx_gauss_kernel_q8(int k, double sigma, uint16_t* out_host);
+
+/* Separable fixed-point filter, the arithmetic of cv2.GaussianBlur on uint8 -- server.py:428:
+ * row pass u8 x Q0.8 -> Q8.8 (exact), column pass -> Q8.16, dst = (acc + 2^15) >> 16, REFLECT_101,
+ * each interleaved channel on its own.  kx_q8 / ky_q8 are HOST arrays of k odd taps each summing to
+ * 256 (every tap <= 256).  Halo rows (r = k/2 each) as described above. */
+int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+                         int64_t src_row_stride, int64_t src_img_stride,
+                         int64_t dst_row_stride, int64_t dst_img_stride,
+                         const uint16_t* kx_q8, const uint16_t* ky_q8, int k,
+                         const uint8_t* top_halo, const uint8_t* bottom_halo);
+
+/* cv2.GaussianBlur(img, (k,k), 0) -- server.py:428: ipx_gauss_kernel_q8 + ipx_sep_filter_q8_u8. */
+int ipx_gaussian_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+                         int64_t src_row_stride, int64_t src_img_stride,
+                         int64_t dst_row_stride, int64_t dst_img_stride, int k,
+                         const uint8_t* top_halo, const uint8_t* bottom_halo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPX_H */

@@ -1,0 +1,261 @@
+"""GPU parity: every libipx entry point (through the ctypes C-ABI) against the CPU oracle, bit-exact.
+
+Bar: all of this path is integer / table arithmetic (the Gaussian is OpenCV's fixed-point one), so every
+comparison is exact equality; the only float32 step (equalizeHist's scale) is compared exactly too.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+import ipx.luts as luts
+import ipx.ops as ops
+
+pytestmark = pytest.mark.gpu
+
+# (h, w): ragged widths, single row/column, sub-16-byte rows, several 1 KiB strips, strip-edge cases
+SHAPES = [(1, 1), (1, 5), (7, 1), (2, 2), (3, 17), (16, 16), (5, 64), (33, 70), (9, 341), (40, 342), (21, 1030),
+          (70, 683), (18, 2051), (130, 96)]
+
+
+def rnd(shape, seed=0):
+    return np.random.default_rng(seed).integers(0, 256, shape, dtype=np.uint8)
+
+
+def dev_t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("cn", [3, 4])
+def test_bgr2gray(dev, shape, cn):
+    img = rnd(shape + (cn,), 1)
+    np.testing.assert_array_equal(host(ops.bgr2gray(dev_t(img, dev))), O.bgr2gray_u8(img))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("cn", [1, 3])
+def test_lut_host_table(dev, shape, cn):
+    img = rnd(shape + ((cn,) if cn > 1 else ()), 2)
+    lut = np.random.default_rng(3).permutation(256).astype(np.uint8)
+    np.testing.assert_array_equal(host(ops.apply_lut(dev_t(img, dev), lut)), lut[img])
+
+
+def test_lut_device_tables_per_image(dev):
+    imgs = rnd((5, 37, 53, 1), 4)
+    tabs = np.stack([np.random.default_rng(i).permutation(256).astype(np.uint8) for i in range(5)])
+    out = host(ops.apply_lut_dev(dev_t(imgs, dev), dev_t(tabs, dev)))
+    for i in range(5):
+        np.testing.assert_array_equal(out[i, :, :, 0], tabs[i][imgs[i, :, :, 0]])
+    out = host(ops.apply_lut_dev(dev_t(imgs, dev), dev_t(tabs[2], dev)))
+    np.testing.assert_array_equal(out, tabs[2][imgs])
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_bgr2gray_lut_fused(dev, shape):
+    img = rnd(shape + (3,), 5)
+    lut = luts.gamma(0.6)
+    np.testing.assert_array_equal(host(ops.bgr2gray_lut(dev_t(img, dev), lut)), lut[O.bgr2gray_u8(img)])
+
+
+@pytest.mark.parametrize("shape", SHAPES + [(600, 700)])
+def test_hist_and_equalize(dev, shape):
+    img = rnd(shape, 6)
+    t = dev_t(img, dev)
+    np.testing.assert_array_equal(host(ops.hist(t)).astype(np.uint32), O.hist_u8(img))
+    out, h, lut = ops.equalize_hist(t, return_aux=True)
+    np.testing.assert_array_equal(host(h)[0].astype(np.uint32), O.hist_u8(img))
+    np.testing.assert_array_equal(host(lut)[0], O.equalize_lut_from_hist(O.hist_u8(img)))
+    np.testing.assert_array_equal(host(out), O.equalize_hist_u8(img))
+
+
+def test_hist_distributions(dev):
+    """all-one-bin (LDS contention worst case), low contrast, two-level, missing low bins."""
+    rng = np.random.default_rng(7)
+    cases = [np.full((257, 300), 255, np.uint8), np.full((64, 64), 0, np.uint8),
+             np.clip(rng.normal(128, 10, (300, 333)), 0, 255).astype(np.uint8),
+             (rng.integers(0, 2, (100, 90)) * 200 + 17).astype(np.uint8),
+             rng.integers(100, 256, (99, 101), dtype=np.uint8)]
+    for img in cases:
+        t = dev_t(img, dev)
+        np.testing.assert_array_equal(host(ops.hist(t)).astype(np.uint32), O.hist_u8(img))
+        np.testing.assert_array_equal(host(ops.equalize_hist(t)), O.equalize_hist_u8(img))
+
+
+def test_equalize_batch_each_image_own_table(dev):
+    imgs = np.stack([np.clip(np.random.default_rng(i).normal(60 + 30 * i, 8 + 5 * i, (45, 67)), 0, 255).astype(np.uint8)
+                     for i in range(6)])[..., None]
+    out = host(ops.equalize_hist(dev_t(imgs, dev)))
+    for i in range(6):
+        np.testing.assert_array_equal(out[i, :, :, 0], O.equalize_hist_u8(imgs[i, :, :, 0]))
+
+
+def test_equalize_lut_from_large_histograms(dev):
+    """float32 scale / int->float rounding at 2^30 pixels: LUT kernel alone."""
+    rng = np.random.default_rng(8)
+    hs = []
+    for i in range(16):
+        p = rng.random(256) ** (1 + i % 4)
+        if i % 3 == 0:
+            p[: rng.integers(1, 200)] = 0
+        h = np.floor(p / p.sum() * ((1 << 30) - 7 * i)).astype(np.int64)
+        hs.append(h)
+    hs.append(np.eye(256, dtype=np.int64)[37] * 12345)                # single-valued image
+    hs.append(np.array([0] * 10 + [1] + [0] * 244 + [1 << 20], np.int64))
+    H = np.stack(hs).astype(np.int32)
+    got = host(ops.equalize_lut(dev_t(H, dev)))
+    for i in range(len(hs)):
+        np.testing.assert_array_equal(got[i], O.equalize_lut_from_hist(hs[i]), err_msg=f"hist {i}")
+
+
+CONV = [("laplacian_sharpen", O.laplacian_sharpen_u8), ("box3", O.box3_u8), ("sobel", O.sobel_u8)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+@pytest.mark.parametrize("name,ref", CONV)
+def test_conv3(dev, shape, cn, name, ref):
+    img = rnd(shape + ((cn,) if cn > 1 else ()), 9)
+    got = host(getattr(ops, name)(dev_t(img, dev)))
+    np.testing.assert_array_equal(got, ref(img))
+
+
+@pytest.mark.parametrize("name,ref", CONV)
+def test_conv3_extremes(dev, name, ref):
+    """saturating inputs: checkerboards of 0/255 hit both clamps of sharpen and the 255 cap of Sobel."""
+    yy, xx = np.mgrid[0:50, 0:1100]
+    for img in (((yy + xx) % 2 * 255).astype(np.uint8), ((yy // 3 + xx // 5) % 2 * 255).astype(np.uint8),
+                np.full((50, 1100), 255, np.uint8)):
+        for a in (img, np.stack([img, 255 - img, img], -1)):
+            np.testing.assert_array_equal(host(getattr(ops, name)(dev_t(a, dev))), ref(a))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (7, 1), (33, 70), (40, 342), (18, 2051), (130, 96)])
+@pytest.mark.parametrize("cn", [1, 3, 4])
+@pytest.mark.parametrize("k", [1, 3, 5, 7, 9, 15, 31])
+def test_gaussian(dev, shape, cn, k):
+    img = rnd(shape + ((cn,) if cn > 1 else ()), 10)
+    np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(img, dev), k)), O.gaussian_blur_u8(img, k))
+
+
+def test_gaussian_c2_and_asymmetric_taps(dev):
+    img = rnd((37, 300, 2), 11)
+    np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(img, dev), 5)), O.gaussian_blur_u8(img, 5))
+    img = rnd((37, 300, 3), 12)
+    kx, ky = [200, 50, 6], [1, 2, 3, 4, 246][:3] + []      # 3 taps each; asymmetric on purpose
+    ky = [10, 240, 6]
+    np.testing.assert_array_equal(host(ops.sep_filter_q8(dev_t(img, dev), kx, ky)), O.sep_filter_q8_u8(img, kx, ky))
+    kx5, ky5 = [1, 2, 3, 4, 246], [100, 50, 6, 60, 40]
+    np.testing.assert_array_equal(host(ops.sep_filter_q8(dev_t(img, dev), kx5, ky5)), O.sep_filter_q8_u8(img, kx5, ky5))
+    k9 = [1, 2, 3, 4, 236, 4, 3, 2, 1]
+    np.testing.assert_array_equal(host(ops.sep_filter_q8(dev_t(img, dev), k9, k9[::-1])), O.sep_filter_q8_u8(img, k9, k9[::-1]))
+
+
+def test_gaussian_max_values_do_not_overflow(dev):
+    img = np.full((40, 1200, 3), 255, np.uint8)
+    for k in (3, 5, 7, 15):
+        np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(img, dev), k)), img)
+
+
+def test_batches_and_strides(dev):
+    """batch > 1, padded rows, padded image stride, unaligned base pointer."""
+    big = rnd((3, 50, 400 * 3 + 7), 13)
+    tb = dev_t(big, dev)
+    view = tb[:, 5:45, 1:1 + 390 * 3].unflatten(2, (390, 3))          # N x 40 x 390 x 3, strided, base + 1
+    ref_in = big[:, 5:45, 1:1 + 390 * 3].reshape(3, 40, 390, 3)
+    for name, ref in CONV + [("g5", lambda a: O.gaussian_blur_u8(a, 5))]:
+        f = (lambda t: ops.gaussian_blur(t, 5)) if name == "g5" else getattr(ops, name)
+        got = host(f(view))
+        for i in range(3):
+            np.testing.assert_array_equal(got[i], ref(ref_in[i]), err_msg=name)
+    got = host(ops.bgr2gray(view))
+    for i in range(3):
+        np.testing.assert_array_equal(got[i, :, :, 0], O.bgr2gray_u8(ref_in[i]))
+    gview = tb[:, 3:47, 3:3 + 1111].unsqueeze(-1)
+    gref = big[:, 3:47, 3:3 + 1111]
+    lut = luts.negative()
+    np.testing.assert_array_equal(host(ops.apply_lut(gview, lut))[..., 0], lut[gref])
+    got = host(ops.equalize_hist(gview))
+    for i in range(3):
+        np.testing.assert_array_equal(got[i, :, :, 0], O.equalize_hist_u8(np.ascontiguousarray(gref[i])))
+
+
+@pytest.mark.parametrize("cn", [1, 3])
+def test_halo_rows_equal_whole_image(dev, cn):
+    """A row shard filtered with exchanged halo rows == the same rows of the whole image filtered at once."""
+    img = rnd((90, 500) + ((cn,) if cn > 1 else ()), 14)
+    t = dev_t(img, dev)
+    for name, ref, r in [("laplacian_sharpen", O.laplacian_sharpen_u8, 1), ("box3", O.box3_u8, 1),
+                         ("sobel", O.sobel_u8, 1), ("g5", lambda a: O.gaussian_blur_u8(a, 5), 2),
+                         ("g9", lambda a: O.gaussian_blur_u8(a, 9), 4)]:
+        whole = ref(img)
+        for (y0, y1) in ((0, 30), (30, 61), (61, 90)):
+            top = t[y0 - r:y0] if y0 > 0 else None
+            bot = t[y1:y1 + r] if y1 < 90 else None
+            if name.startswith("g"):
+                got = ops.gaussian_blur(t[y0:y1], int(name[1:]), top_halo=top, bottom_halo=bot)
+            else:
+                got = getattr(ops, name)(t[y0:y1], top_halo=top, bottom_halo=bot)
+            np.testing.assert_array_equal(host(got), whole[y0:y1], err_msg=f"{name} rows {y0}:{y1}")
+
+
+def test_golden_server_cases_on_device(dev, golden):
+    """The real server.py outputs (tests/golden) reproduced by host-built table + device apply."""
+    g, meta = golden
+    from test_oracle_golden import _lut_for
+    n = 0
+    for c in meta["cases"]:
+        if c["status"] != 200:
+            continue
+        img, out = g["in_" + c["input"]], g["out_" + c["name"]]
+        t = dev_t(img, dev)
+        mode = c["mode"] or "gray8"
+        if mode in ("log", "logarithmic", "logrithmic"):
+            present = host(ops.hist(t))                       # device histogram feeds s.max()
+            lut = luts.log(float(c["form"].get("c", "2.0")), present)
+        else:
+            lut = _lut_for(mode, c["form"], img)
+        np.testing.assert_array_equal(host(ops.apply_lut(t, lut)), out, err_msg=c["name"])
+        n += 1
+    assert n >= 60
+
+
+def test_full_size_properties(dev):
+    """BASELINE configs at full size through size-independent properties (no oracle pass at 4K x 32)."""
+    n, h, w = 4, 2160, 3840
+    g = torch.Generator(device="cpu").manual_seed(0)
+    bgr = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, generator=g).to(dev)
+    gray = ops.bgr2gray(bgr)
+    hs = ops.hist(gray)
+    assert hs.shape == (n, 256) and bool((hs.sum(1) == h * w).all())         # checksum of the histogram
+    # histogram agrees with torch's own count
+    for i in range(n):
+        assert torch.equal(hs[i].to(torch.int64), torch.bincount(gray[i].flatten().to(torch.int64), minlength=256))
+    eq = ops.equalize_hist(gray)
+    # equalization is a monotone map of the gray levels: order of pixels is preserved
+    a, b = gray[0, 100:200, 100:900, 0].flatten().to(torch.int32), eq[0, 100:200, 100:900, 0].flatten().to(torch.int32)
+    o = torch.argsort(a, stable=True)
+    assert bool((b[o][1:] >= b[o][:-1]).all())
+    # negative twice is the identity; LUT linearity of composition
+    neg = ops.apply_lut(gray, luts.negative())
+    assert torch.equal(ops.apply_lut(neg, luts.negative()), gray)
+    # constant image is a fixed point of every convolution; batch entries are independent
+    const = torch.full((2, h, w, 3), 93, dtype=torch.uint8, device=dev)
+    for f in (ops.laplacian_sharpen, ops.box3, lambda t: ops.gaussian_blur(t, 5), lambda t: ops.gaussian_blur(t, 15)):
+        assert torch.equal(f(const), const)
+    assert int(ops.sobel(const).max()) == 0
+    s_all = ops.laplacian_sharpen(bgr)
+    assert torch.equal(s_all[2], ops.laplacian_sharpen(bgr[2]))
+    # one 4K image against the oracle on a band of rows (oracle on the band + 1 halo row each side)
+    band = bgr[1, 999:1101].cpu().numpy()
+    np.testing.assert_array_equal(s_all[1, 1000:1100].cpu().numpy(), O.laplacian_sharpen_u8(band)[1:-1])
+    g5 = ops.gaussian_blur(bgr, 5)
+    band = bgr[3, 0:66].cpu().numpy()
+    np.testing.assert_array_equal(g5[3, 0:64].cpu().numpy(), O.gaussian_blur_u8(band, 5)[:64])
+    sb = ops.sobel(gray)
+    band = gray[0, 2060:2160, :, 0].cpu().numpy()
+    np.testing.assert_array_equal(sb[0, 2061:2160, :, 0].cpu().numpy(), O.sobel_u8(band)[1:])

@@ -1,0 +1,148 @@
+"""CPU suite: the oracle against the golden vectors made from the real server.py, the two restatements
+against each other, the host LUT builders against both, and known-answer anchors."""
+import numpy as np
+import pytest
+
+import oracle as O
+import coracle as CO
+import ipx.luts as luts
+
+
+def _expected(O, img, mode, form):
+    if mode in ("gamma", "powerlaw", "power-law"):
+        return O.gamma_u8(img, float(form.get("gamma") or form.get("gamma_value") or form.get("g")))
+    if mode == "negative":
+        return O.negative_u8(img)
+    if mode in ("log", "logarithmic", "logrithmic"):
+        return O.log_u8(img, float(form.get("c", "2.0")))
+    if mode in ("piecewise", "piecewise_linear", "stretch"):
+        return O.piecewise_u8(img, *[int(form[k]) for k in ("r1", "s1", "r2", "s2")])
+    return img          # gray8 / default / unknown mode on a gray input
+
+
+def _lut_for(mode, form, img):
+    if mode in ("gamma", "powerlaw", "power-law"):
+        return luts.gamma(float(form.get("gamma") or form.get("gamma_value") or form.get("g")))
+    if mode == "negative":
+        return luts.negative()
+    if mode in ("log", "logarithmic", "logrithmic"):
+        return luts.log(float(form.get("c", "2.0")), np.bincount(img.ravel(), minlength=256))
+    if mode in ("piecewise", "piecewise_linear", "stretch"):
+        return luts.piecewise(*luts.piecewise_clamp(*[int(form[k]) for k in ("r1", "s1", "r2", "s2")]))
+    return np.arange(256, dtype=np.uint8)
+
+
+def test_oracle_matches_real_server_outputs(golden):
+    g, meta = golden
+    n = 0
+    for c in meta["cases"]:
+        if c["status"] != 200:
+            continue
+        img, out = g["in_" + c["input"]], g["out_" + c["name"]]
+        np.testing.assert_array_equal(_expected(O, img, c["mode"] or "gray8", c["form"]), out, err_msg=c["name"])
+        n += 1
+    assert n >= 60
+
+
+def test_host_luts_match_real_server_outputs(golden):
+    """LUT built on 256 levels, then applied == the reference's whole-image evaluation (bit-exact)."""
+    g, meta = golden
+    for c in meta["cases"]:
+        if c["status"] != 200:
+            continue
+        img, out = g["in_" + c["input"]], g["out_" + c["name"]]
+        lut = _lut_for(c["mode"] or "gray8", c["form"], img)
+        np.testing.assert_array_equal(lut[img], out, err_msg=c["name"])
+
+
+def test_lee_filter_matches_real_server(golden):
+    g, _ = golden
+    for w in (3, 5, 7):
+        np.testing.assert_array_equal(O.lee_filter_u8(g["in_lee"], w), g[f"out_lee_{w}"])
+
+
+def test_piecewise_probe_from_survey():
+    lut = luts.piecewise(*luts.piecewise_clamp(70, 10, 180, 245))
+    assert [int(lut[i]) for i in (0, 70, 71, 180, 181, 255)] == [0, 10, 12, 245, 245, 255]
+
+
+def test_threshold_semantics():
+    img = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    assert np.array_equal(O.threshold_u8(img, 128), np.where(img > 128, 255, 0))
+    assert O.threshold_u8(img, -1).min() == 255 and O.threshold_u8(img, 255).max() == 0
+    for T in (-5, 0, 1, 127, 128, 254, 255, 300):
+        np.testing.assert_array_equal(luts.threshold(T)[img], O.threshold_u8(img, T))
+
+
+@pytest.mark.parametrize("shape", [(37, 53, 3), (20, 31), (1, 7, 3), (5, 1), (2, 2, 3), (33, 70, 4), (3, 3)])
+def test_c_and_numpy_restatements_agree(shape):
+    rng = np.random.default_rng(sum(shape))
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    if img.ndim == 3:
+        np.testing.assert_array_equal(O.bgr2gray_u8(img), CO.bgr2gray_u8(img))
+    np.testing.assert_array_equal(O.laplacian_sharpen_u8(img), CO.laplacian_sharpen_u8(img))
+    np.testing.assert_array_equal(O.box3_u8(img), CO.box3_u8(img))
+    np.testing.assert_array_equal(O.sobel_u8(img), CO.sobel_u8(img))
+    for k in (1, 3, 5, 7, 9, 15, 31):
+        np.testing.assert_array_equal(O.gauss_kernel_q8(k), CO.gauss_kernel_q8(k))
+        np.testing.assert_array_equal(O.gaussian_blur_u8(img, k), CO.gaussian_blur_u8(img, k))
+    gray = img if img.ndim == 2 else np.ascontiguousarray(img[..., 0])
+    np.testing.assert_array_equal(O.hist_u8(gray), CO.hist_u8(gray))
+    np.testing.assert_array_equal(O.equalize_hist_u8(gray), CO.equalize_hist_u8(gray))
+
+
+def test_gauss_kernels_known_answers():
+    assert O.gauss_kernel_q8(3).tolist() == [64, 128, 64]
+    assert O.gauss_kernel_q8(5).tolist() == [16, 64, 96, 64, 16]
+    assert O.gauss_kernel_q8(7).tolist() == [8, 28, 56, 72, 56, 28, 8]
+    for k in range(1, 64, 2):
+        q = O.gauss_kernel_q8(k)
+        assert int(q.sum()) == 256 and np.array_equal(q, q[::-1])
+
+
+def test_identity_anchors():
+    """constant images are fixed points of sharpen / equalize / Gaussian / box."""
+    for v in (0, 77, 255):
+        c = np.full((9, 11), v, np.uint8)
+        c3 = np.full((9, 11, 3), v, np.uint8)
+        for f in (O.laplacian_sharpen_u8, O.box3_u8, O.equalize_hist_u8, lambda a: O.gaussian_blur_u8(a, 5),
+                  lambda a: O.gaussian_blur_u8(a, 31)):
+            np.testing.assert_array_equal(f(c), c)
+        np.testing.assert_array_equal(O.laplacian_sharpen_u8(c3), c3)
+        assert O.sobel_u8(c).max() == 0
+        np.testing.assert_array_equal(O.bgr2gray_u8(c3), c)       # coefficients sum to 2^15
+
+
+def test_equalize_uniform_levels_known_answer():
+    N = 256 * 40
+    img = np.repeat(np.arange(256, dtype=np.uint8), 40).reshape(80, 128)
+    lut = O.equalize_lut_from_hist(O.hist_u8(img))
+    exp = np.rint(np.arange(256) * (N / 256) * np.float32(255.0) / np.float32(N - N / 256))
+    exp[0] = 0
+    np.testing.assert_array_equal(lut, exp.astype(np.uint8))
+
+
+def test_equalize_lut_float32_at_2_30_pixels():
+    rng = np.random.default_rng(3)
+    p = rng.random(256)
+    hist = np.floor(p / p.sum() * (1 << 30)).astype(np.int64)
+    hist[255] += (1 << 30) - hist.sum()
+    np.testing.assert_array_equal(O.equalize_lut_from_hist(hist), CO.equalize_lut_from_hist(hist.astype(np.uint32)))
+
+
+def test_gaussian_fixed_point_vs_float_within_1lsb_small_k():
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (40, 44), dtype=np.uint8)
+    for k in (3, 5, 7):
+        d = np.abs(O.gaussian_blur_u8(img, k).astype(int) - O.gaussian_blur_float_ref(img, k).astype(int))
+        assert d.max() <= 1
+
+
+def test_denoise_stats_thresholds():
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    s = O.denoise_stats(img)
+    assert s["suggested_method"] in ("median", "lee", "bilateral")
+    sp = np.full((64, 64), 128, np.uint8)
+    sp[::4, ::4] = 0
+    assert O.denoise_stats(sp)["suggested_method"] == "median"
