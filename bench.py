@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- megapixels/s of the image hot path on MI355X (BASELINE.json metric).
+
+Workload at every N (weak scaling, one process per GPU, no data-path collective): BASELINE.json configs[1],
+"3840x2160 RGB image, 5x5 Gaussian + Sobel edge + hist-eq", as a batch of --batch such images already resident
+in HBM.  One step = for every image of the batch:
+    gauss5  = cv2.GaussianBlur(bgr,(5,5),0)                 (colour, 6 B/px algorithmic)
+    gray    = cv2.cvtColor(bgr, BGR2GRAY)                   (4 B/px)
+    sobel   = 3x3 Sobel magnitude of gray                   (2 B/px)   <- the "conv3x3" of the metric
+    eq      = cv2.equalizeHist(gray)                        (2 B/px)
+value = (ranks x batch x 8.2944 MP) / step time: pixels pushed through the whole pipeline per second.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the 5x5 Gaussian) by its algorithmic
+bytes; `kernels` lists every op of the step the same way; `cpu_baseline` times the C oracle (a port, not the
+reference: OpenCV is absent) on a bounded sample of the same workload on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "image-processing_amd"))
+
+H, W = 2160, 3840
+MP = H * W / 1e6
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(sample_images: int):
+    """C oracle (oracle/_build/liboracle.so, OpenMP) over `sample_images` 4K frames of the same pipeline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import coracle as CO
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    rng = np.random.default_rng(0)
+    imgs = [rng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(sample_images)]
+    CO.gaussian_blur_u8(imgs[0][:64], 5)        # load + warm the library
+    t0 = time.perf_counter()
+    for im in imgs:
+        CO.gaussian_blur_u8(im, 5)
+        g = CO.bgr2gray_u8(im)
+        CO.sobel_u8(g)
+        CO.equalize_hist_u8(g)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_images * MP / dt, 2), "unit": "megapixels/s", "cores": threads, "kind": "port",
+            "sample": f"{sample_images} x 3840x2160 RGB frames, same 4-op pipeline, C oracle with OpenMP "
+                      f"({dt:.1f} s of CPU work); host has {os.cpu_count()} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="4K RGB frames per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="frames timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ipx._lib as L
+    import ipx.ops as ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    L.load()
+    L.call("ipx_check_device")
+
+    B = args.batch
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    bgr = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=g).to(dev)
+
+    def step():
+        g5 = ops.gaussian_blur(bgr, 5)
+        gray = ops.bgr2gray(bgr)
+        sb = ops.sobel(gray)
+        eq = ops.equalize_hist(gray)
+        return g5, sb, eq
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * MP / (dt / args.steps)
+
+    # ---- per-kernel durations, HIP events on the launch stream (torch's current stream) ----------------
+    def time_op(fn, reps=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3          # seconds per launch
+
+    out = None
+    if rank == 0:
+        gray = ops.bgr2gray(bgr)
+        g5_out = torch.empty_like(bgr)
+        px = B * H * W
+        ops_tab = [
+            ("gaussian5_bgr", "sep_small_kernel<3,5>", 6, lambda: ops.gaussian_blur(bgr, 5)),
+            ("bgr2gray", "gray_kernel<3,false>", 4, lambda: ops.bgr2gray(bgr)),
+            ("sobel3_gray", "conv3_kernel<SOBEL,1>", 2, lambda: ops.sobel(gray)),
+            ("equalize_hist_gray", "hist_partial+hist_finish+lut_kernel", 2, lambda: ops.equalize_hist(gray)),
+            ("laplacian_sharpen_bgr", "conv3_kernel<SHARPEN,3>", 6, lambda: ops.laplacian_sharpen(bgr)),
+            ("lut_gray", "lut_kernel<true>", 2, lambda: ops.apply_lut(gray, list(range(255, -1, -1)))),
+        ]
+        del g5_out
+        kernels = {}
+        for name, kern, bpp, fn in ops_tab:
+            s = time_op(fn)
+            gbs = px * bpp / s / 1e9
+            kernels[name] = {"kernel": kern, "us_per_launch": round(s * 1e6, 1), "algorithmic_B_per_px": bpp,
+                             "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4),
+                             "MPps": round(px / s / 1e6, 1)}
+        dom = kernels["gaussian5_bgr"]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("gaussian5_bgr")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": dom["frac_of_8TBps"], "traffic": traffic,
+                    "algorithmic_bytes_per_launch": px * 6, "launch_us": dom["us_per_launch"]}
+        cpu = cpu_baseline(args.cpu_sample) if (args.cpu_sample > 0 and world == 1) else None
+        out = {
+            "metric": "megapixels/sec (whole node) for conv3x3 + hist-eq on 4K RGB; % of HBM roofline",
+            "value": round(value, 1), "unit": "megapixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: 3840x2160 RGB, 5x5 Gaussian + Sobel (3x3) + hist-eq "
+                                   "(incl. BGR->gray), batch resident in HBM",
+                       "batch_per_gpu": B, "image": "3840x2160x3 u8 BGR interleaved",
+                       "parallelism": f"{world} x one process per GPU, images sharded, no collective"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,73 +1,60 @@
 // ipx_conv.hip -- 3x3 convolutions (Laplacian sharpen, box, Sobel) and the separable fixed-point
 // Gaussian of cv2.GaussianBlur, for 1..4 interleaved uint8 channels, BORDER_REFLECT_101.
 //
-// Work decomposition ("strip walker"): an image row is L = w*c bytes.  One WAVE owns a strip of 64 lanes x
-// 16 bytes = 1 KiB of the row and walks down a segment of rows.  Per input row a lane loads its own 16 bytes
-// plus the few halo bytes left and right of them (same cache lines its neighbour lanes load: L1 hits), keeps
-// the vertical window in registers, and stores 16 output bytes per row.  Every input byte is fetched from HBM
-// once (plus r halo rows per segment); nothing is staged twice.  Neighbouring strips are consecutive work items
-// and the block->item map is XCD-aware so that they share one L2.
+// Work decomposition ("strip walker"): an image row is L = w*c bytes.  One WAVE owns a strip of up to 64 lanes x
+// 16 bytes of the row and walks down a segment of rows.  Per input row a lane loads its own 16 bytes plus the
+// few halo bytes left and right of them (the cache lines its neighbour lanes load: L1 hits), turns them into
+// packed 16-bit "field pairs" (v_perm_b32) and does the horizontal part of the filter with packed 16-bit VALU ops;
+// the vertical window of those row features lives in registers.  Loads run U rows ahead of the arithmetic.
+// Every input byte is fetched from HBM once (plus r halo rows per segment); nothing is staged twice.
+// The lanes of the main region never touch the left/right image border: the first 16 bytes of every row and the
+// ragged tail behind the last full lane are computed by "border" blocks appended to the same launch with plain
+// per-byte code (REFLECT_101 in pixel space).  Tiny images are all border.
+// Neighbouring strips are consecutive work items and the block->item map is XCD-aware so that they share an L2.
 // Kernels larger than 7 taps go through the generic two-pass path at the bottom (row pass to a Q8.8 scratch
 // image, column pass back to uint8).
 #include "ipx_common.h"
+#include <stdlib.h>
 #include <vector>
 
 namespace {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = 64 * kWavesPerBlock;
-constexpr int kStripBytes = 64 * 16;
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short ss2 __attribute__((ext_vector_type(2)));
 
 struct ConvGeom {
     int h, w, L;                       // rows, pixels per row, bytes per row
     int64_t s_row, s_img, d_row, d_img;
-    int nstrips, seg_rows, nsegs;
-    unsigned nitems;                   // n * nsegs * nstrips
+    int nlanes;                        // 16-byte lanes of the main region: bytes [16, 16 + 16*nlanes)
+    int lanes_per_strip, nstrips, seg_rows, nsegs;
+    unsigned nitems;                   // n * nsegs * nstrips wave work items
+    unsigned main_blocks;              // blocks [0, main_blocks) walk strips, the rest do border bytes
+    int nb;                            // border bytes per row: [0,16) and [16 + 16*nlanes, L)  (or all of L)
+    unsigned border_total;             // n * h * nb
     const uint8_t* top;                // r halo rows above row 0 (row -r first), or null = reflect
     const uint8_t* bot;                // r halo rows below row h-1, or null = reflect
 };
+
+// Source row `y` of the image (y may lie outside [0,h)): halo row if provided, else REFLECT_101.
+__device__ __forceinline__ const uint8_t* row_ptr(const ConvGeom& g, const uint8_t* simg, int y, int r)
+{
+    if (y < 0 && g.top) return g.top + (int64_t)(r + y) * g.s_row;
+    if (y >= g.h && g.bot) return g.bot + (int64_t)(y - g.h) * g.s_row;
+    return simg + (int64_t)reflect101(y, g.h) * g.s_row;
+}
 
 template <int C, int R>
 struct Win {                            // bytes [b0 - 4*HD, b0 + 16 + 4*HD) of one row, as dwords
     static constexpr int HD = (R * C + 3) / 4;
     static constexpr int ND = 4 + 2 * HD;
     uint32_t w[ND];
-    __device__ __forceinline__ uint32_t at(int i) const   // byte at offset i from b0; i static after unroll
-    {
-        const int k = i + 4 * HD;
-        return (w[k >> 2] >> (8 * (k & 3))) & 255u;
-    }
-};
-
-// Source row `y` of the image (y may lie outside [0,h)): halo row if provided, else REFLECT_101.
-template <int R>
-__device__ __forceinline__ const uint8_t* row_ptr(const ConvGeom& g, const uint8_t* simg, int y)
-{
-    if (y < 0 && g.top) return g.top + (int64_t)(R + y) * g.s_row;
-    if (y >= g.h && g.bot) return g.bot + (int64_t)(y - g.h) * g.s_row;
-    return simg + (int64_t)reflect101(y, g.h) * g.s_row;
-}
-
-// Per-lane byte offsets (from the row pointer) of the window bytes of a lane that touches the left/right image
-// border or the ragged end of the row: REFLECT_101 in pixel space.  Row-independent, so computed once per item.
-template <int C, int R>
-struct Gather {
-    int o[Win<C, R>::ND * 4];
-    __device__ __forceinline__ void init(int b0, int wpx)
-    {
-        constexpr int HD = Win<C, R>::HD;
-#pragma unroll
-        for (int i = 0; i < Win<C, R>::ND * 4; ++i) {
-            const int b = b0 + i - 4 * HD;
-            int px = (b + 64 * C) / C - 64;                 // floor division, b >= -64*C
-            const int ch = b - px * C;
-            o[i] = reflect101(px, wpx) * C + ch;
-        }
-    }
 };
 
 template <int C, int R>
-__device__ __forceinline__ void load_win_fast(Win<C, R>& W, const uint8_t* rp, int b0)
+__device__ __forceinline__ void load_win(Win<C, R>& W, const uint8_t* rp, int b0)
 {
     constexpr int HD = Win<C, R>::HD;
     __builtin_memcpy(&W.w[0], rp + b0 - 4 * HD, 4 * HD);
@@ -75,76 +62,177 @@ __device__ __forceinline__ void load_win_fast(Win<C, R>& W, const uint8_t* rp, i
     __builtin_memcpy(&W.w[HD + 4], rp + b0 + 16, 4 * HD);
 }
 
+// Field pair (byte p, byte p+2) of the window, zero-extended to 2 x u16; p is relative to b0 and static.
 template <int C, int R>
-__device__ __forceinline__ void load_win_edge(Win<C, R>& W, const uint8_t* rp, int b0, bool interior, const Gather<C, R>& G)
+__device__ __forceinline__ us2 fld(const Win<C, R>& W, int p)
 {
-    if (interior) {
-        load_win_fast<C, R>(W, rp, b0);
+    const int q = p + 4 * Win<C, R>::HD;
+    const int d = q >> 2, j = q & 3;
+    const uint32_t lo = W.w[d];
+    uint32_t v;
+    if (j == 0) {
+        v = lo & 0x00ff00ffu;
     } else {
-#pragma unroll
-        for (int d = 0; d < Win<C, R>::ND; ++d) {
-            uint32_t word = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) word |= (uint32_t)rp[G.o[4 * d + k]] << (8 * k);
-            W.w[d] = word;
-        }
+        const uint32_t hi = j >= 2 ? W.w[d + 1] : lo;          // byte p+2 lives in the next dword
+        v = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)j | ((uint32_t)(j + 2) << 16));
     }
+    return __builtin_bit_cast(us2, v);
 }
 
-__device__ __forceinline__ void store_out(uint8_t* dp, int b0, int L, u32x4 o)
+// The 8 field pairs of a lane's 16 output bytes: slot s = 2*k + parity covers bytes (4k+parity, 4k+parity+2).
+__device__ __forceinline__ constexpr int slot_p(int s) { return 4 * (s >> 1) + (s & 1); }
+
+__device__ __forceinline__ uint32_t pack_fields(us2 even, us2 odd)      // fields hold 0..255
 {
-    if (b0 + 16 <= L) {
-        st16(dp + b0, o);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (b0 + i < L) dp[b0 + i] = (uint8_t)(o[i >> 2] >> (8 * (i & 3)));
-    }
+    return __builtin_bit_cast(uint32_t, even) | (__builtin_bit_cast(uint32_t, odd) << 8);
 }
 
-__device__ __forceinline__ uint32_t clamp255(int v) { return (uint32_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+// D = lo16(p) * c + acc   /   D = hi16(p) * c + acc      (c in an SGPR)
+__device__ __forceinline__ uint32_t mad_lo16(uint32_t p, uint32_t c, uint32_t acc)
+{
+    uint32_t d;
+    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(d) : "v"(p), "s"(c), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ uint32_t mad_hi16(uint32_t p, uint32_t c, uint32_t acc)
+{
+    uint32_t d;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(p), "s"(c), "v"(acc));
+    return d;
+}
+
+// Output dword from four 32-bit accumulators whose result byte sits in bits 16..23:
+// eL -> byte 0, oL -> byte 1, eH -> byte 2, oH -> byte 3.
+__device__ __forceinline__ uint32_t pack_acc(uint32_t eL, uint32_t oL, uint32_t eH, uint32_t oH)
+{
+    return __builtin_amdgcn_perm(oL, eL, 0x0c0c0602u) | __builtin_amdgcn_perm(oH, eH, 0x06020c0cu);
+}
+
+__device__ __forceinline__ ss2 pk_max(ss2 a, ss2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ ss2 pk_min(ss2 a, ss2 b) { return __builtin_elementwise_min(a, b); }
 
 enum { OP_SHARPEN = 0, OP_BOX = 1, OP_SOBEL = 2 };
 
-template <int OP, int C>
-__device__ __forceinline__ u32x4 conv3_row(const Win<C, 1>& a, const Win<C, 1>& b, const Win<C, 1>& c)
-{
-    u32x4 o;
+// ---- 3x3 operators as (row feature, vertical combine) pairs ------------------------------------------------
+template <int OP, int C> struct Conv3;
+
+template <int C> struct Conv3<OP_SHARPEN, C> {          // clip(5c - n - s - e - w)        server.py:270-276
+    struct Feat { us2 c[8]; ss2 t[8]; };               // centre fields; t = 5c - (e + w)
+    static __device__ __forceinline__ void feat(Feat& f, const Win<C, 1>& W)
+    {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        uint32_t word = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = 4 * k + j;
-            uint32_t v;
-            if (OP == OP_SHARPEN) {          // clip(5c - n - s - e - w)            server.py:270-276
-                const int s = (int)(a.at(i) + c.at(i) + b.at(i - C) + b.at(i + C));
-                v = clamp255(5 * (int)b.at(i) - s);
-            } else if (OP == OP_BOX) {       // round(sum9 / 9): never a tie -> (sum + 4) / 9
-                const uint32_t s = a.at(i - C) + a.at(i) + a.at(i + C) + b.at(i - C) + b.at(i) + b.at(i + C) +
-                                   c.at(i - C) + c.at(i) + c.at(i + C);
-                v = (s + 4u) / 9u;
-            } else {                         // min(255, |gx| + |gy|)
-                const int l = (int)(a.at(i - C) + 2 * b.at(i - C) + c.at(i - C));
-                const int r = (int)(a.at(i + C) + 2 * b.at(i + C) + c.at(i + C));
-                const int t = (int)(a.at(i - C) + 2 * a.at(i) + a.at(i + C));
-                const int u = (int)(c.at(i - C) + 2 * c.at(i) + c.at(i + C));
-                const int gx = r - l, gy = u - t;
-                const int m = (gx < 0 ? -gx : gx) + (gy < 0 ? -gy : gy);
-                v = (uint32_t)(m > 255 ? 255 : m);
-            }
-            word |= v << (8 * j);
+        for (int s = 0; s < 8; ++s) {
+            const int p = slot_p(s);
+            f.c[s] = fld<C, 1>(W, p);
+            const us2 hs = fld<C, 1>(W, p - C) + fld<C, 1>(W, p + C);
+            f.t[s] = __builtin_bit_cast(ss2, (us2)(f.c[s] * (unsigned short)5 - hs));
         }
-        o[k] = word;
     }
-    return o;
+    static __device__ __forceinline__ u32x4 out(const Feat& a, const Feat& b, const Feat& c)
+    {
+        u32x4 o;
+        us2 r[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            ss2 v = b.t[s] - __builtin_bit_cast(ss2, (us2)(a.c[s] + c.c[s]));
+            v = pk_min(pk_max(v, (ss2)(0)), (ss2)(255));
+            r[s] = __builtin_bit_cast(us2, v);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack_fields(r[2 * k], r[2 * k + 1]);
+        return o;
+    }
+};
+
+template <int C> struct Conv3<OP_BOX, C> {              // round(sum9 / 9): never a tie -> (sum + 4) / 9
+    struct Feat { us2 s3[8]; };
+    static __device__ __forceinline__ void feat(Feat& f, const Win<C, 1>& W)
+    {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int p = slot_p(s);
+            f.s3[s] = fld<C, 1>(W, p - C) + fld<C, 1>(W, p) + fld<C, 1>(W, p + C);
+        }
+    }
+    static __device__ __forceinline__ u32x4 out(const Feat& a, const Feat& b, const Feat& c)
+    {
+        u32x4 o;
+        uint32_t lo[8], hi[8];
+        const uint32_t m = __builtin_amdgcn_readfirstlane(7282u);      // (x * 7282) >> 16 == x / 9 for x < 3640*9
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const uint32_t sum = __builtin_bit_cast(uint32_t, (us2)(a.s3[s] + b.s3[s] + c.s3[s]));
+            lo[s] = mad_lo16(sum, m, 4u * 7282u);
+            hi[s] = mad_hi16(sum, m, 4u * 7282u);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack_acc(lo[2 * k], lo[2 * k + 1], hi[2 * k], hi[2 * k + 1]);
+        return o;
+    }
+};
+
+template <int C> struct Conv3<OP_SOBEL, C> {            // min(255, |gx| + |gy|)
+    struct Feat { ss2 d[8]; us2 s[8]; };               // d = right - left, s = left + 2 centre + right
+    static __device__ __forceinline__ void feat(Feat& f, const Win<C, 1>& W)
+    {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int p = slot_p(s);
+            const us2 l = fld<C, 1>(W, p - C), m = fld<C, 1>(W, p), r = fld<C, 1>(W, p + C);
+            f.d[s] = __builtin_bit_cast(ss2, (us2)(r - l));
+            f.s[s] = l + r + m * (unsigned short)2;
+        }
+    }
+    static __device__ __forceinline__ u32x4 out(const Feat& a, const Feat& b, const Feat& c)
+    {
+        u32x4 o;
+        us2 r[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const ss2 gx = a.d[s] + c.d[s] + b.d[s] * (short)2;
+            const ss2 gy = __builtin_bit_cast(ss2, (us2)(c.s[s] - a.s[s]));
+            const ss2 m = pk_max(gx, -gx) + pk_max(gy, -gy);            // <= 2040, no overflow
+            r[s] = __builtin_bit_cast(us2, pk_min(m, (ss2)(255)));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack_fields(r[2 * k], r[2 * k + 1]);
+        return o;
+    }
+};
+
+// Per-byte evaluation of the same operators (border bytes, tiny images).
+template <int OP>
+__device__ __forceinline__ uint32_t conv3_byte(const uint8_t* r0, const uint8_t* r1, const uint8_t* r2, int xl, int xc, int xr)
+{
+    const int a = r0[xl], b = r0[xc], c = r0[xr], d = r1[xl], e = r1[xc], f = r1[xr], g = r2[xl], h = r2[xc], i = r2[xr];
+    int v;
+    if (OP == OP_SHARPEN) { v = 5 * e - (b + h + d + f); v = v < 0 ? 0 : v > 255 ? 255 : v; }
+    else if (OP == OP_BOX) { v = (a + b + c + d + e + f + g + h + i + 4) / 9; }
+    else {
+        const int gx = (c + 2 * f + i) - (a + 2 * d + g), gy = (g + 2 * h + i) - (a + 2 * b + c);
+        v = (gx < 0 ? -gx : gx) + (gy < 0 ? -gy : gy);
+        if (v > 255) v = 255;
+    }
+    return (uint32_t)v;
 }
 
-// Decode the wave's work item.  Returns false if the wave has nothing to do.
-__device__ __forceinline__ bool wave_item(const ConvGeom& g, unsigned& img, int& y0, int& y1, int& sb0)
+// Decode a border thread: false if out of range.  b = byte in the row, y = row, img.
+__device__ __forceinline__ bool border_item(const ConvGeom& g, unsigned bblock, unsigned& img, int& y, int& b)
 {
-    const unsigned wave = threadIdx.x >> 6;
-    const unsigned item = xcd_remap(blockIdx.x, gridDim.x) * kWavesPerBlock + wave;
+    const unsigned t = bblock * kThreads + threadIdx.x;
+    if (t >= g.border_total) return false;
+    const unsigned j = t % (unsigned)g.nb, rest = t / (unsigned)g.nb;
+    y = (int)(rest % (unsigned)g.h);
+    img = rest / (unsigned)g.h;
+    b = g.nlanes > 0 ? ((int)j < 16 ? (int)j : 16 * g.nlanes + (int)j) : (int)j;
+    return true;
+}
+
+// Decode the wave's strip item; all values wave-uniform (SGPRs).
+__device__ __forceinline__ bool wave_item(const ConvGeom& g, unsigned& img, int& y0, int& y1, int& lane0)
+{
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned item = xcd_remap(blockIdx.x, g.main_blocks) * kWavesPerBlock + wave;
     if (item >= g.nitems) return false;
     const unsigned strip = item % (unsigned)g.nstrips;
     const unsigned rest = item / (unsigned)g.nstrips;
@@ -152,128 +240,79 @@ __device__ __forceinline__ bool wave_item(const ConvGeom& g, unsigned& img, int&
     img = rest / (unsigned)g.nsegs;
     y0 = (int)seg * g.seg_rows;
     y1 = y0 + g.seg_rows < g.h ? y0 + g.seg_rows : g.h;
-    sb0 = (int)(strip * kStripBytes);                       // first byte of the wave's strip
+    lane0 = (int)strip * g.lanes_per_strip;
     return true;
-}
-
-// EDGE = false: every lane of the wave is interior (vector loads only, U rows in flight).
-// EDGE = true : the strip touches the left/right border or the ragged row end; lanes that do gather bytes.
-template <int OP, int C, bool EDGE>
-__device__ __forceinline__ void conv3_walk(const ConvGeom& g, const uint8_t* simg, uint8_t* dimg, int y0, int y1, int b0)
-{
-    typedef Win<C, 1> W1;
-    constexpr int U = EDGE ? 1 : 4;                        // rows loaded ahead per step
-    const bool interior = !EDGE || (b0 >= 4 * W1::HD && b0 + 16 + 4 * W1::HD <= g.L);
-    Gather<C, 1> G;
-    if (EDGE && !interior) G.init(b0, g.w);
-    auto load = [&](W1& W, int y) {
-        const uint8_t* rp = row_ptr<1>(g, simg, y);
-        if (EDGE) load_win_edge<C, 1>(W, rp, b0, interior, G);
-        else load_win_fast<C, 1>(W, rp, b0);
-    };
-    W1 a, b;
-    load(a, y0 - 1);
-    load(b, y0);
-    for (int y = y0; y < y1; y += U) {
-        W1 nx[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j)                        // rows past the segment re-load its last needed row
-            load(nx[j], y + 1 + j <= y1 ? y + 1 + j : y1);
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            if (y + j < y1) store_out(dimg + (int64_t)(y + j) * g.d_row, b0, g.L, conv3_row<OP, C>(a, b, nx[j]));
-            a = b;
-            b = nx[j];
-        }
-    }
 }
 
 template <int OP, int C>
 __global__ __launch_bounds__(kThreads) void conv3_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                          ConvGeom g)
 {
-    unsigned img; int y0, y1, sb0;
-    if (!wave_item(g, img, y0, y1, sb0)) return;
-    const int b0 = sb0 + (int)(threadIdx.x & 63u) * 16;
-    if (b0 >= g.L) return;
+    if (blockIdx.x >= g.main_blocks) {                       // ---- border bytes, one per thread
+        unsigned img; int y, b;
+        if (!border_item(g, blockIdx.x - g.main_blocks, img, y, b)) return;
+        const uint8_t* simg = src + (int64_t)img * g.s_img;
+        const int px = b / C, ch = b - px * C;
+        const int xl = reflect101(px - 1, g.w) * C + ch, xr = reflect101(px + 1, g.w) * C + ch;
+        dst[(int64_t)img * g.d_img + (int64_t)y * g.d_row + b] = (uint8_t)conv3_byte<OP>(
+            row_ptr(g, simg, y - 1, 1), row_ptr(g, simg, y, 1), row_ptr(g, simg, y + 1, 1), xl, b, xr);
+        return;
+    }
+    unsigned img; int y0, y1, lane0;
+    if (!wave_item(g, img, y0, y1, lane0)) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    if (lane >= g.lanes_per_strip || lane0 + lane >= g.nlanes) return;
+    const int b0 = 16 + 16 * (lane0 + lane);
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
-    constexpr int HB = 4 * Win<C, 1>::HD;
-    if (sb0 >= HB && sb0 + kStripBytes + HB <= g.L) conv3_walk<OP, C, false>(g, simg, dimg, y0, y1, b0);
-    else conv3_walk<OP, C, true>(g, simg, dimg, y0, y1, b0);
+    typedef Win<C, 1> W1;
+    typedef Conv3<OP, C> Op;
+    constexpr int U = 4;                                     // rows per step; loads run one step ahead
+
+    typename Op::Feat fa, fb;
+    {
+        W1 wa, wb;
+        load_win<C, 1>(wa, row_ptr(g, simg, y0 - 1, 1), b0);
+        load_win<C, 1>(wb, row_ptr(g, simg, y0, 1), b0);
+        Op::feat(fa, wa);
+        Op::feat(fb, wb);
+    }
+    W1 nx[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) load_win<C, 1>(nx[j], row_ptr(g, simg, y0 + 1 + j <= y1 ? y0 + 1 + j : y1, 1), b0);
+    for (int y = y0; y < y1; y += U) {
+        W1 nn[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {                        // next step's rows (rows past the segment: re-read y1)
+            const int yy = y + U + 1 + j;
+            load_win<C, 1>(nn[j], row_ptr(g, simg, yy <= y1 ? yy : y1, 1), b0);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            typename Op::Feat fc;
+            Op::feat(fc, nx[j]);
+            if (y + j < y1) st16(dimg + (int64_t)(y + j) * g.d_row + b0, Op::out(fa, fb, fc));
+            fa = fb;
+            fb = fc;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) nx[j] = nn[j];
+    }
 }
 
 // ---- separable fixed-point filter, K <= 7, register sliding window ---------------------------------------
 template <int K> struct Taps { uint32_t kx[K]; uint32_t ky[K]; };
 
 template <int C, int K>
-__device__ __forceinline__ void hpass(uint32_t (&h)[16], const Win<C, K / 2>& W, const Taps<K>& t)
+__device__ __forceinline__ void hpass(us2 (&h)[8], const Win<C, K / 2>& W, const Taps<K>& t)
 {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        uint32_t acc = 0;
+    for (int s = 0; s < 8; ++s) {
+        const int p = slot_p(s);
+        us2 acc = fld<C, K / 2>(W, p - C * (K / 2)) * (unsigned short)t.kx[0];
 #pragma unroll
-        for (int j = 0; j < K; ++j) acc = __umul24(t.kx[j], W.at(i + C * (j - K / 2))) + acc;
-        h[i] = acc;                                           // Q8.8, <= 255*256
-    }
-}
-
-template <int C, int K, bool EDGE>
-__device__ __forceinline__ void sep_walk(const ConvGeom& g, const Taps<K>& t, const uint8_t* simg, uint8_t* dimg,
-                                         int y0, int y1, int b0)
-{
-    constexpr int R = K / 2;
-    typedef Win<C, R> WR;
-    constexpr int U = EDGE ? 1 : (K <= 3 ? 3 : 2);         // rows loaded ahead per step; must divide the K-unroll
-    const bool interior = !EDGE || (b0 >= 4 * WR::HD && b0 + 16 + 4 * WR::HD <= g.L);
-    Gather<C, R> G;
-    if (EDGE && !interior) G.init(b0, g.w);
-    auto load = [&](WR& W, int y) {
-        const uint8_t* rp = row_ptr<R>(g, simg, y);
-        if (EDGE) load_win_edge<C, R>(W, rp, b0, interior, G);
-        else load_win_fast<C, R>(W, rp, b0);
-    };
-
-    uint32_t hw[K][16];                                      // ring of K row-pass results (statically indexed)
-#pragma unroll
-    for (int s = 0; s < K - 1; ++s) {                        // prologue: rows y0-R .. y0+R-1
-        WR W;
-        load(W, y0 - R + s);
-        hpass<C, K>(hw[s], W, t);
-    }
-    for (int y = y0; y < y1; y += K) {
-#pragma unroll
-        for (int s0 = 0; s0 < K; s0 += U) {
-            WR nx[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int s = s0 + u;
-                if (s < K) load(nx[u], y + s < y1 ? y + s + R : y1 - 1 + R);   // clamp: rows nobody needs are not read
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int s = s0 + u;
-                if (s >= K) continue;
-                hpass<C, K>(hw[(K - 1 + s) % K], nx[u], t);
-                if (y + s < y1) {
-                    u32x4 o;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        uint32_t word = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            uint32_t acc = 32768u;
-#pragma unroll
-                            for (int i = 0; i < K; ++i) acc = __umul24(t.ky[i], hw[(s + i) % K][4 * k + j]) + acc;
-                            acc >>= 16;                       // taps sum to 256 -> acc <= 255
-                            word |= (acc > 255u ? 255u : acc) << (8 * j);
-                        }
-                        o[k] = word;
-                    }
-                    store_out(dimg + (int64_t)(y + s) * g.d_row, b0, g.L, o);
-                }
-            }
-        }
+        for (int j = 1; j < K; ++j) acc += fld<C, K / 2>(W, p + C * (j - K / 2)) * (unsigned short)t.kx[j];
+        h[s] = acc;                                           // Q8.8, <= 255*256: no 16-bit overflow
     }
 }
 
@@ -281,15 +320,78 @@ template <int C, int K>
 __global__ __launch_bounds__(kThreads) void sep_small_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                              ConvGeom g, Taps<K> t)
 {
-    unsigned img; int y0, y1, sb0;
-    if (!wave_item(g, img, y0, y1, sb0)) return;
-    const int b0 = sb0 + (int)(threadIdx.x & 63u) * 16;
-    if (b0 >= g.L) return;
+    constexpr int R = K / 2;
+    if (blockIdx.x >= g.main_blocks) {                       // ---- border bytes, one per thread
+        unsigned img; int y, b;
+        if (!border_item(g, blockIdx.x - g.main_blocks, img, y, b)) return;
+        const uint8_t* simg = src + (int64_t)img * g.s_img;
+        const int px = b / C, ch = b - px * C;
+        int xo[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) xo[j] = reflect101(px + j - R, g.w) * C + ch;
+        uint32_t acc = 32768u;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const uint8_t* rp = row_ptr(g, simg, y + i - R, R);
+            uint32_t hsum = 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) hsum += t.kx[j] * rp[xo[j]];
+            acc += t.ky[i] * hsum;
+        }
+        dst[(int64_t)img * g.d_img + (int64_t)y * g.d_row + b] = (uint8_t)(acc >> 16);
+        return;
+    }
+    unsigned img; int y0, y1, lane0;
+    if (!wave_item(g, img, y0, y1, lane0)) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    if (lane >= g.lanes_per_strip || lane0 + lane >= g.nlanes) return;
+    const int b0 = 16 + 16 * (lane0 + lane);
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
-    constexpr int HB = 4 * Win<C, K / 2>::HD;
-    if (sb0 >= HB && sb0 + kStripBytes + HB <= g.L) sep_walk<C, K, false>(g, t, simg, dimg, y0, y1, b0);
-    else sep_walk<C, K, true>(g, t, simg, dimg, y0, y1, b0);
+    typedef Win<C, R> WR;
+
+    us2 hw[K][8];                                            // ring of K row-pass results (statically indexed)
+#pragma unroll
+    for (int s = 0; s < K - 1; ++s) {                        // prologue: rows y0-R .. y0+R-1
+        WR W;
+        load_win<C, R>(W, row_ptr(g, simg, y0 - R + s, R), b0);
+        hpass<C, K>(hw[s], W, t);
+    }
+    const int ylast = y1 - 1 + R;                            // last source row anybody needs
+    WR nx[K];
+#pragma unroll
+    for (int s = 0; s < K; ++s) load_win<C, R>(nx[s], row_ptr(g, simg, y0 + s + R <= ylast ? y0 + s + R : ylast, R), b0);
+    for (int y = y0; y < y1; y += K) {
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            hpass<C, K>(hw[(K - 1 + s) % K], nx[s], t);
+            {                                                 // refill the slot just consumed: row y + K + s + R
+                const int yy = y + K + s + R;
+                load_win<C, R>(nx[s], row_ptr(g, simg, yy <= ylast ? yy : ylast, R), b0);
+            }
+            if (y + s < y1) {
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t lo[2], hi[2];
+#pragma unroll
+                    for (int par = 0; par < 2; ++par) {
+                        uint32_t al = 32768u, ah = 32768u;
+#pragma unroll
+                        for (int i = 0; i < K; ++i) {
+                            const uint32_t hv = __builtin_bit_cast(uint32_t, hw[(s + i) % K][2 * k + par]);
+                            al = mad_lo16(hv, t.ky[i], al);
+                            ah = mad_hi16(hv, t.ky[i], ah);
+                        }
+                        lo[par] = al;                         // taps sum to 256 -> (acc >> 16) <= 255
+                        hi[par] = ah;
+                    }
+                    o[k] = pack_acc(lo[0], lo[1], hi[0], hi[1]);
+                }
+                st16(dimg + (int64_t)(y + s) * g.d_row + b0, o);
+            }
+        }
+    }
 }
 
 // ---- generic two-pass path (any odd K <= IPX_MAX_GAUSS_K) -----------------------------------------------
@@ -302,12 +404,7 @@ __global__ __launch_bounds__(256) void sep_rows_kernel(const uint8_t* __restrict
     const int r = K / 2;
     const int trow = blockIdx.y;                              // 0 .. h + 2r - 1
     const unsigned img = blockIdx.z;
-    const int y = trow - r;
-    const uint8_t* simg = src + (int64_t)img * g.s_img;
-    const uint8_t* rp;
-    if (y < 0 && g.top) rp = g.top + (int64_t)(r + y) * g.s_row;
-    else if (y >= g.h && g.bot) rp = g.bot + (int64_t)(y - g.h) * g.s_row;
-    else rp = simg + (int64_t)reflect101(y, g.h) * g.s_row;
+    const uint8_t* rp = row_ptr(g, src + (int64_t)img * g.s_img, trow - r, r);
     uint16_t* tp = tmp + ((int64_t)img * (g.h + 2 * r) + trow) * (int64_t)g.L;
     for (int b = blockIdx.x * 256 + threadIdx.x; b < g.L; b += gridDim.x * 256) {
         const int px = b / C, ch = b - px * C;
@@ -340,7 +437,14 @@ __global__ __launch_bounds__(256) void sep_cols_kernel(const uint16_t* __restric
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
-int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// hd4 = 4 * ceil(r*c/4): halo bytes a main-region lane reads on either side (<= 16)
+int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c, int r,
                    int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
                    const uint8_t* top, const uint8_t* bot)
 {
@@ -350,28 +454,43 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
     g.h = h; g.w = w; g.L = w * c;
     g.s_row = s_row; g.s_img = s_img; g.d_row = d_row; g.d_img = d_img;
     g.top = top; g.bot = bot;
-    g.nstrips = (g.L + kStripBytes - 1) / kStripBytes;
-    // rows per segment: aim at >= ~6k waves on the chip, but keep segments >= 16 rows (halo re-reads <= 2r/16)
-    const int64_t waves_if_one_row = (int64_t)n * g.nstrips * h;
-    int64_t seg = waves_if_one_row / 6144;
-    if (seg < 16) seg = 16;
-    if (seg > 256) seg = 256;
+    const int hd4 = 4 * ((r * c + 3) / 4);
+    // main-region lane i covers bytes [16 + 16 i, 32 + 16 i) and reads hd4 bytes on either side of them
+    g.nlanes = g.L >= 32 + hd4 ? (g.L - 32 - hd4) / 16 + 1 : 0;
+    g.nstrips = (g.nlanes + 63) / 64;
+    g.lanes_per_strip = g.nstrips ? (g.nlanes + g.nstrips - 1) / g.nstrips : 0;
+    // rows per segment: short enough for >= ~4 waves of work per wave slot, long enough to amortise the
+    // 2r halo rows every segment re-reads
+    int seg = env_int("IPX_SEG_ROWS", 0);
+    if (seg <= 0) {
+        const int64_t rows_total = (int64_t)n * (g.nstrips ? g.nstrips : 1) * h;
+        seg = (int)(rows_total / 16384);
+        const int lo = r <= 1 ? 24 : 16 * r + 16, hi = 128;
+        if (seg < lo) seg = lo;
+        if (seg > hi) seg = hi;
+    }
     if (seg > h) seg = h;
-    g.seg_rows = (int)seg;
-    g.nsegs = (h + g.seg_rows - 1) / g.seg_rows;
+    g.seg_rows = seg;
+    g.nsegs = (h + seg - 1) / seg;
     const uint64_t items = (uint64_t)n * g.nsegs * g.nstrips;
-    if (items > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many work items", fn);
+    g.nb = g.nlanes > 0 ? 16 + (g.L - 16 - 16 * g.nlanes) : g.L;
+    const uint64_t btotal = (uint64_t)n * h * g.nb;
+    if (items > 0x3fffffffull || btotal > 0xffffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many work items", fn);
     g.nitems = (unsigned)items;
+    g.main_blocks = (unsigned)((items + kWavesPerBlock - 1) / kWavesPerBlock);
+    g.border_total = (unsigned)btotal;
     return IPX_OK;
 }
+
+unsigned conv_grid(const ConvGeom& g) { return g.main_blocks + (g.border_total + kThreads - 1) / kThreads; }
 
 template <int OP>
 int launch_conv3(const char* fn, void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
                  int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* top, const uint8_t* bot)
 {
     ConvGeom g;
-    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, top, bot)) return rc;
-    const dim3 grid((g.nitems + kWavesPerBlock - 1) / kWavesPerBlock), block(kThreads);
+    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, 1, s_row, s_img, d_row, d_img, top, bot)) return rc;
+    const dim3 grid(conv_grid(g)), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
     switch (c) {
         case 1: hipLaunchKernelGGL((conv3_kernel<OP, 1>), grid, block, 0, st, src, dst, g); break;
@@ -389,8 +508,7 @@ void launch_sep_small(hipStream_t st, const uint8_t* src, uint8_t* dst, const Co
 {
     Taps<K> t;
     for (int i = 0; i < K; ++i) { t.kx[i] = kx[i]; t.ky[i] = ky[i]; }
-    const dim3 grid((g.nitems + kWavesPerBlock - 1) / kWavesPerBlock), block(kThreads);
-    hipLaunchKernelGGL((sep_small_kernel<C, K>), grid, block, 0, st, src, dst, g, t);
+    hipLaunchKernelGGL((sep_small_kernel<C, K>), dim3(conv_grid(g)), dim3(kThreads), 0, st, src, dst, g, t);
 }
 
 template <int K>
@@ -437,10 +555,11 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
                          const uint8_t* top_halo, const uint8_t* bottom_halo)
 {
     const char* fn = "ipx_sep_filter_q8_u8";
-    ConvGeom g;
-    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, top_halo, bottom_halo)) return rc;
+    ipx_clear_error();
     if (!kx_q8 || !ky_q8) return ipx_fail(IPX_ERR_INVALID, "%s: null taps", fn);
     if (k < 1 || (k & 1) == 0 || k > IPX_MAX_GAUSS_K) return ipx_fail(IPX_ERR_INVALID, "%s: k=%d must be odd and in 1..%d", fn, k, IPX_MAX_GAUSS_K);
+    ConvGeom g;
+    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, k / 2, s_row, s_img, d_row, d_img, top_halo, bottom_halo)) return rc;
     unsigned sx = 0, sy = 0;
     for (int i = 0; i < k; ++i) {
         if (kx_q8[i] > 256 || ky_q8[i] > 256) return ipx_fail(IPX_ERR_INVALID, "%s: tap %d exceeds 256 (Q0.8 of 1.0)", fn, i);
@@ -484,4 +603,4 @@ int ipx_gaussian_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
                                 top_halo, bottom_halo);
 }
 
-}  // extern "C"
+}  // namespace
