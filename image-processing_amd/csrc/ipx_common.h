@@ -37,8 +37,48 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // accesses and hipcc lowers these to global_load/store_dwordx4 (checked in the .s).
 __device__ __forceinline__ u32x4 ld16(const uint8_t* p) { u32x4 v; __builtin_memcpy(&v, p, 16); return v; }
 __device__ __forceinline__ void st16(uint8_t* p, u32x4 v) { __builtin_memcpy(p, &v, 16); }
-__device__ __forceinline__ u32x2 ld8(const uint8_t* p) { u32x2 v; __builtin_memcpy(&v, p, 8); return v; }
-__device__ __forceinline__ uint32_t ld4(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+// Streaming ("nt") forms for data that is touched once: measured on MI355X, a block-contiguous copy with nt loads
+// and stores runs 6.2-6.4 TB/s against 5.6 TB/s with the default cache policy (scripts/dev/membench.hip).
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_u __attribute__((aligned(1)));
+typedef u32x2 u32x2_u __attribute__((aligned(1)));
+typedef uint32_t u32_u __attribute__((aligned(1)));
+__device__ __forceinline__ u32x4 ld16_nt(const uint8_t* p) { return __builtin_nontemporal_load((const u32x4_u*)p); }
+__device__ __forceinline__ void st16_nt(uint8_t* p, u32x4 v) { __builtin_nontemporal_store(v, (u32x4_u*)p); }
+template <bool NT> __device__ __forceinline__ u32x4 ld16x(const uint8_t* p) { return NT ? ld16_nt(p) : ld16(p); }
+template <bool NT> __device__ __forceinline__ void st16x(uint8_t* p, u32x4 v) { if (NT) st16_nt(p, v); else st16(p, v); }
+
+// Cache policy of the streaming kernels: small and medium working sets are left to the default policy (the next
+// kernel of a pipeline finds them in the 256 MiB Infinity Cache); very large ones are streamed with nt.  Measured on
+// 16 x 4K frames (scripts/opbench.py): nt wins on an 800 MB table pass (132 vs 143 us) and loses on a 530 MB
+// BGR->gray (106 vs 98 us) and on 266 MB gray passes.  Threshold in bytes of source + destination touched by one
+// call, default 600 MiB; IPX_NT_BYTES overrides it (0 = always nt, huge = never).
+bool ipx_use_nt(uint64_t bytes_touched);
+
+// gray = (3735 B + 19235 G + 9798 R + 16384) >> 15   (OpenCV RGB2Gray<uchar>, Q15)
+__device__ __forceinline__ uint32_t gray_q15(uint32_t b, uint32_t g, uint32_t r)
+{
+    return (3735u * b + 19235u * g + 9798u * r + 16384u) >> 15;
+}
+
+template <int C> struct PxVec;                                   // 16 pixels of C interleaved bytes
+template <> struct PxVec<3> { u32x4 q[3]; };
+template <> struct PxVec<4> { u32x4 q[4]; };
+
+template <int C, bool NT>
+__device__ __forceinline__ void load_px16(PxVec<C>& p, const uint8_t* s)
+{
+#pragma unroll
+    for (int i = 0; i < C; ++i) p.q[i] = ld16x<NT>(s + 16 * i);
+}
+
+template <int C>
+__device__ __forceinline__ uint32_t px_byte(const PxVec<C>& p, int byte_index)   // static after unrolling
+{
+    return (p.q[byte_index >> 4][(byte_index >> 2) & 3] >> (8 * (byte_index & 3))) & 255u;
+}
 
 // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
 __host__ __device__ __forceinline__ int reflect101(int p, int len)

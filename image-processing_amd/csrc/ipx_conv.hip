@@ -15,6 +15,9 @@
 // image, column pass back to uint8).
 #include "ipx_common.h"
 #include <stdlib.h>
+#ifndef IPX_CONV_NT_LOADS
+#define IPX_CONV_NT_LOADS 0
+#endif
 #include <vector>
 
 namespace {
@@ -57,8 +60,13 @@ template <int C, int R>
 __device__ __forceinline__ void load_win(Win<C, R>& W, const uint8_t* rp, int b0)
 {
     constexpr int HD = Win<C, R>::HD;
-    __builtin_memcpy(&W.w[0], rp + b0 - 4 * HD, 4 * HD);
+#if IPX_CONV_NT_LOADS
+    const u32x4 c = ld16_nt(rp + b0);
+    __builtin_memcpy(&W.w[HD], &c, 16);
+#else
     __builtin_memcpy(&W.w[HD], rp + b0, 16);
+#endif
+    __builtin_memcpy(&W.w[0], rp + b0 - 4 * HD, 4 * HD);
     __builtin_memcpy(&W.w[HD + 4], rp + b0 + 16, 4 * HD);
 }
 
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(const uint8_t* __restri
         for (int j = 0; j < U; ++j) {
             typename Op::Feat fc;
             Op::feat(fc, nx[j]);
-            if (y + j < y1) st16(dimg + (int64_t)(y + j) * g.d_row + b0, Op::out(fa, fb, fc));
+            if (y + j < y1) st16_nt(dimg + (int64_t)(y + j) * g.d_row + b0, Op::out(fa, fb, fc));
             fa = fb;
             fb = fc;
         }
@@ -388,7 +396,7 @@ __global__ __launch_bounds__(kThreads) void sep_small_kernel(const uint8_t* __re
                     }
                     o[k] = pack_acc(lo[0], lo[1], hi[0], hi[1]);
                 }
-                st16(dimg + (int64_t)(y + s) * g.d_row + b0, o);
+                st16_nt(dimg + (int64_t)(y + s) * g.d_row + b0, o);
             }
         }
     }
@@ -465,7 +473,7 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
     if (seg <= 0) {
         const int64_t rows_total = (int64_t)n * (g.nstrips ? g.nstrips : 1) * h;
         seg = (int)(rows_total / 16384);
-        const int lo = r <= 1 ? 24 : 16 * r + 16, hi = 128;
+        const int lo = r <= 1 ? 16 : r == 2 ? 24 : 48, hi = 128;      // measured optima on 16 x 4K (scripts/opbench.py)
         if (seg < lo) seg = lo;
         if (seg > hi) seg = hi;
     }

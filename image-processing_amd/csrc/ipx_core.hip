@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -38,6 +39,15 @@ int ipx_check_image_args(const char* fn, const void* src, const void* dst, int n
             return ipx_fail(IPX_ERR_INVALID, "%s: dst_img_stride %lld smaller than one image", fn, (long long)dst_img_stride);
     }
     return IPX_OK;
+}
+
+bool ipx_use_nt(uint64_t bytes_touched)
+{
+    static const long long thr = [] {
+        const char* v = getenv("IPX_NT_BYTES");
+        return v && *v ? atoll(v) : (long long)600 << 20;
+    }();
+    return (long long)bytes_touched >= thr;
 }
 
 extern "C" {

@@ -15,7 +15,7 @@ extern "C" int ipx_lut_dev_u8(void*, const uint8_t*, uint8_t*, int, int, int, in
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;                  // 8 waves share one 32 KiB LDS histogram: 4 blocks = 32 waves per CU
 constexpr int kUnroll = 4;
 constexpr int kChunk = kThreads * 16;
 constexpr int kUnit = kChunk * kUnroll;          // 16 KiB of pixels per block step
@@ -36,6 +36,7 @@ __device__ __forceinline__ void count4(uint32_t* s_hist, uint32_t x, unsigned co
     atomicAdd(&s_hist[((x >> 24) << 5) | copy], 1u);
 }
 
+template <bool NT>
 __global__ __launch_bounds__(kThreads) void hist_partial_kernel(const uint8_t* __restrict__ src, HistGeom g,
                                                                 uint32_t* __restrict__ partial)
 {
@@ -47,7 +48,10 @@ __global__ __launch_bounds__(kThreads) void hist_partial_kernel(const uint8_t* _
 
     const unsigned img = blockIdx.y;
     const uint8_t* simg = src + (int64_t)img * g.s_img;
-    for (unsigned u = blockIdx.x; u < g.units_per_img; u += gridDim.x) {
+    // each block takes a CONTIGUOUS range of units (streams faster than striding over the image)
+    const unsigned u_begin = (unsigned)((uint64_t)g.units_per_img * blockIdx.x / gridDim.x);
+    const unsigned u_end = (unsigned)((uint64_t)g.units_per_img * (blockIdx.x + 1) / gridDim.x);
+    for (unsigned u = u_begin; u < u_end; ++u) {
         const unsigned row = u / g.units_per_row;
         const int64_t col0 = (int64_t)(u - row * g.units_per_row) * kUnit + (int64_t)tid * 16;
         const uint8_t* sp = simg + (int64_t)row * g.s_row;
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void hist_partial_kernel(const uint8_t* _
 #pragma unroll
         for (int j = 0; j < kUnroll; ++j) {
             const int64_t c = col0 + (int64_t)j * kChunk;
-            if (c + 16 <= g.len) v[j] = ld16(sp + c);
+            if (c + 16 <= g.len) v[j] = ld16x<NT>(sp + c);
         }
 #pragma unroll
         for (int j = 0; j < kUnroll; ++j) {
@@ -70,44 +74,126 @@ __global__ __launch_bounds__(kThreads) void hist_partial_kernel(const uint8_t* _
     }
     __syncthreads();
     // fold the 32 copies of bin `tid`; lane reads copy (j + tid) % 32 -> bank (j + tid) % 32: conflict-free
-    uint32_t sum = 0;
+    if (tid < 256) {
+        uint32_t sum = 0;
 #pragma unroll
-    for (int j = 0; j < kCopies; ++j) sum += s_hist[(tid << 5) | ((j + tid) & 31u)];
-    partial[((size_t)img * gridDim.x + blockIdx.x) * 256 + tid] = sum;
+        for (int j = 0; j < kCopies; ++j) sum += s_hist[(tid << 5) | ((j + tid) & 31u)];
+        partial[((size_t)img * gridDim.x + blockIdx.x) * 256 + tid] = sum;
+    }
+}
+
+
+// Fused cvtColor(BGR2GRAY) + histogram: reads BGR(A), writes the gray image (default cache policy: the table pass
+// re-reads it right away) and counts it.  Same LDS layout and partial-sum output as hist_partial_kernel.
+struct GrayHistGeom {
+    int rows;
+    int64_t len;                       // pixels per row (after collapsing dense images to one long row)
+    int64_t s_row, s_img, g_row, g_img;
+    unsigned units_per_row, units_per_img;
+};
+constexpr int kGUnit = kChunk * 2;     // pixels per block step: 2 x (3|4) x 16 B loads in flight per lane
+
+template <int C, bool NT>
+__global__ __launch_bounds__(kThreads) void gray_hist_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ gray,
+                                                             GrayHistGeom g, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t s_hist[256 * kCopies];
+    const unsigned tid = threadIdx.x, copy = tid & 31u;
+#pragma unroll
+    for (int i = 0; i < 256 * kCopies / kThreads; ++i) s_hist[i * kThreads + tid] = 0;
+    __syncthreads();
+    const unsigned img = blockIdx.y;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* gimg = gray + (int64_t)img * g.g_img;
+    const unsigned u_begin = (unsigned)((uint64_t)g.units_per_img * blockIdx.x / gridDim.x);
+    const unsigned u_end = (unsigned)((uint64_t)g.units_per_img * (blockIdx.x + 1) / gridDim.x);
+    for (unsigned u = u_begin; u < u_end; ++u) {
+        const unsigned row = u / g.units_per_row;
+        const int64_t px0 = (int64_t)(u - row * g.units_per_row) * kGUnit + (int64_t)tid * 16;
+        const uint8_t* sp = simg + (int64_t)row * g.s_row;
+        uint8_t* gp = gimg + (int64_t)row * g.g_row;
+        PxVec<C> p[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t x = px0 + (int64_t)j * kChunk;
+            if (x + 16 <= g.len) load_px16<C, NT>(p[j], sp + x * C);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t x = px0 + (int64_t)j * kChunk;
+            if (x + 16 <= g.len) {
+                u32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int px = 4 * k + i;
+                        word |= gray_q15(px_byte<C>(p[j], px * C), px_byte<C>(p[j], px * C + 1), px_byte<C>(p[j], px * C + 2)) << (8 * i);
+                    }
+                    o[k] = word;
+                    count4(s_hist, word, copy);
+                }
+                st16(gp + x, o);
+            } else if (x < g.len) {
+                for (int64_t q = x; q < g.len; ++q) {
+                    const uint8_t* s3 = sp + q * C;
+                    const uint32_t y = gray_q15(s3[0], s3[1], s3[2]);
+                    gp[q] = (uint8_t)y;
+                    atomicAdd(&s_hist[(y << 5) | copy], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < kCopies; ++j) sum += s_hist[(tid << 5) | ((j + tid) & 31u)];
+        partial[((size_t)img * gridDim.x + blockIdx.x) * 256 + tid] = sum;
+    }
 }
 
 // One block per image: hist[bin] = sum over that image's partial blocks; optional equalization LUT.
 // OpenCV histogram.cpp equalizeHist(): i0 = first non-zero bin; hist[i0]==total -> constant image maps to i0;
 // scale = 255.f/(total-hist[i0]); lut[i0]=0; lut[i>i0] = saturate_cast<uchar>(cvRound(float(sum_i)*scale)).
-__global__ __launch_bounds__(kThreads) void hist_finish_kernel(const uint32_t* __restrict__ partial, unsigned nparts,
+constexpr int kFinishGroups = 4;                             // 4 x 256 threads share the partial-sum latency chain
+__global__ __launch_bounds__(256 * kFinishGroups) void hist_finish_kernel(const uint32_t* __restrict__ partial, unsigned nparts,
                                                                const uint32_t* __restrict__ hist_in,
                                                                uint32_t* __restrict__ hist_out,
                                                                uint8_t* __restrict__ lut_out)
 {
     __shared__ uint32_t s_scan[2][256];
+    __shared__ uint32_t s_part[kFinishGroups][256];
     __shared__ int s_i0;
-    const unsigned tid = threadIdx.x, img = blockIdx.x;
+    const unsigned tid = threadIdx.x & 255u, grp = threadIdx.x >> 8, img = blockIdx.x;   // (own block size: 1024)
     uint32_t h = 0;
     if (partial) {
         const uint32_t* p = partial + (size_t)img * nparts * 256 + tid;
-        unsigned b = 0;
-        for (; b + 8 <= nparts; b += 8) {
+        unsigned b = grp;
+        for (; b + 7 * kFinishGroups < nparts; b += 8 * kFinishGroups) {
             uint32_t t[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) t[k] = p[(size_t)(b + k) * 256];
+            for (int k = 0; k < 8; ++k) t[k] = p[(size_t)(b + k * kFinishGroups) * 256];
 #pragma unroll
             for (int k = 0; k < 8; ++k) h += t[k];
         }
-        for (; b < nparts; ++b) h += p[(size_t)b * 256];
+        for (; b < nparts; b += kFinishGroups) h += p[(size_t)b * 256];
+        s_part[grp][tid] = h;
+        __syncthreads();
+        h = 0;
+#pragma unroll
+        for (int k = 0; k < kFinishGroups; ++k) h += s_part[k][tid];
     } else {
         h = hist_in[(size_t)img * 256 + tid];
     }
+    if (grp != 0) return;                                    // groups 1.. only helped with the partial sums
     if (hist_out) hist_out[(size_t)img * 256 + tid] = h;
     if (!lut_out) return;
 
     if (tid == 0) s_i0 = 256;
     s_scan[0][tid] = h;
-    __syncthreads();
+    __syncthreads();                                         // (exited waves no longer count at the barrier)
     if (h != 0) atomicMin(&s_i0, (int)tid);
     int cur = 0;                                             // Hillis-Steele inclusive scan over 256 bins
 #pragma unroll
@@ -152,7 +238,7 @@ unsigned blocks_per_image(int n, int h, int w)
 {
     const uint64_t bytes = (uint64_t)h * (uint64_t)w;
     uint64_t by_work = (bytes + 65535) / 65536;
-    uint64_t by_chip = (1280 + (uint64_t)n - 1) / (uint64_t)n;
+    uint64_t by_chip = (1024 + (uint64_t)n - 1) / (uint64_t)n;   // 256 CUs x 4 resident blocks: one even round
     uint64_t b = by_work < by_chip ? by_work : by_chip;
     return (unsigned)(b < 1 ? 1 : b);
 }
@@ -188,7 +274,11 @@ int launch_partial(hipStream_t st, const uint8_t* src, int n, int h, int w, int6
     unsigned bpi = blocks_per_image(n, h, w);
     if (bpi > g.units_per_img) bpi = g.units_per_img;     // strided rows: fewer units than bytes/64K suggests
     *nparts = bpi;
-    hipLaunchKernelGGL(hist_partial_kernel, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, partial);
+    // the histogram pass reads what the table pass re-reads right after: keep small batches in the Infinity Cache
+    if (ipx_use_nt(2ull * (uint64_t)n * h * w))
+        hipLaunchKernelGGL(hist_partial_kernel<true>, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, partial);
+    else
+        hipLaunchKernelGGL(hist_partial_kernel<false>, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, partial);
     IPX_LAUNCH_CHECK("hist_partial_kernel");
     return IPX_OK;
 }
@@ -222,7 +312,7 @@ int ipx_hist_u8(void* stream, const uint8_t* src, int n, int h, int w, int64_t s
     unsigned nparts = 0;
     int rc = launch_partial(st, src, n, h, w, src_row_stride, src_img_stride, ws.partial, &nparts);
     if (rc == IPX_OK) {
-        hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(kThreads), 0, st, ws.partial, nparts,
+        hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, st, ws.partial, nparts,
                            (const uint32_t*)nullptr, hist_dev, (uint8_t*)nullptr);
         if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "launch of hist_finish_kernel failed");
     }
@@ -238,7 +328,7 @@ int ipx_equalize_lut_u8(void* stream, const uint32_t* hist_dev, int n, uint8_t* 
     ipx_clear_error();
     if (!hist_dev || !lut_dev) return ipx_fail(IPX_ERR_INVALID, "ipx_equalize_lut_u8: null pointer");
     if (n <= 0) return ipx_fail(IPX_ERR_INVALID, "ipx_equalize_lut_u8: n=%d must be positive", n);
-    hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(kThreads), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, (hipStream_t)stream,
                        (const uint32_t*)nullptr, 0u, hist_dev, (uint32_t*)nullptr, lut_dev);
     IPX_LAUNCH_CHECK("hist_finish_kernel");
     return IPX_OK;
@@ -266,13 +356,66 @@ int ipx_equalize_hist_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     unsigned nparts = 0;
     int rc = launch_partial(st, src, n, h, w, src_row_stride, src_img_stride, ws.partial, &nparts);
     if (rc == IPX_OK) {
-        hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(kThreads), 0, st, ws.partial, nparts,
+        hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, st, ws.partial, nparts,
                            (const uint32_t*)nullptr, hist_out_dev, lut);
         if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "launch of hist_finish_kernel failed");
     }
     if (rc == IPX_OK)
         rc = ipx_lut_dev_u8(stream, src, dst, n, h, w, 1, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride,
                             lut, 256);
+    if (own) {
+        hipError_t e = hipFreeAsync(own, st);
+        if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
+    }
+    return rc;
+}
+
+int ipx_bgr2gray_equalize_u8(void* stream, const uint8_t* src, uint8_t* gray, uint8_t* dst, int n, int h, int w, int src_channels,
+                             int64_t src_row_stride, int64_t src_img_stride, int64_t gray_row_stride, int64_t gray_img_stride,
+                             int64_t dst_row_stride, int64_t dst_img_stride,
+                             uint32_t* hist_out_dev, uint8_t* lut_out_dev, void* workspace, size_t workspace_bytes)
+{
+    const char* fn = "ipx_bgr2gray_equalize_u8";
+    if (src_channels != 3 && src_channels != 4) {
+        ipx_clear_error();
+        return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: src_channels=%d (3 = BGR or 4 = BGRA expected)", fn, src_channels);
+    }
+    if (int rc = ipx_check_image_args(fn, src, gray, n, h, w, src_channels, 1, src_row_stride, src_img_stride,
+                                      gray_row_stride, gray_img_stride)) return rc;
+    if (int rc = ipx_check_image_args(fn, gray, dst, n, h, w, 1, 1, gray_row_stride, gray_img_stride,
+                                      dst_row_stride, dst_img_stride)) return rc;
+    if (int rc = check_hist_args(fn, gray, n, h, w, gray_row_stride, gray_img_stride)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t need = workspace_layout(n, h, w, nullptr, nullptr);
+    void* own = nullptr;
+    if (!workspace) {
+        IPX_HIP(hipMallocAsync(&own, need, st));
+        workspace = own;
+    } else if (workspace_bytes < need) {
+        return ipx_fail(IPX_ERR_INVALID, "%s: workspace %zu < %zu bytes needed", fn, workspace_bytes, need);
+    }
+    Workspace ws;
+    workspace_layout(n, h, w, &ws, (uint8_t*)workspace);
+    uint8_t* lut = lut_out_dev ? lut_out_dev : ws.lut;
+    GrayHistGeom g;
+    g.rows = h; g.len = w; g.s_row = src_row_stride; g.s_img = src_img_stride; g.g_row = gray_row_stride; g.g_img = gray_img_stride;
+    if (src_row_stride == (int64_t)w * src_channels && gray_row_stride == w) { g.rows = 1; g.len = (int64_t)w * h; }
+    g.units_per_row = ipx_div_up((uint64_t)g.len, kGUnit);
+    g.units_per_img = (unsigned)g.rows * g.units_per_row;
+    unsigned bpi = blocks_per_image(n, h, w);
+    if (bpi > g.units_per_img) bpi = g.units_per_img;
+    const bool nt = ipx_use_nt((uint64_t)n * h * w * src_channels);
+    auto k = src_channels == 3 ? (nt ? gray_hist_kernel<3, true> : gray_hist_kernel<3, false>)
+                               : (nt ? gray_hist_kernel<4, true> : gray_hist_kernel<4, false>);
+    hipLaunchKernelGGL(k, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, gray, g, ws.partial);
+    int rc = hipGetLastError() == hipSuccess ? IPX_OK : ipx_fail(IPX_ERR_HIP, "%s: launch of gray_hist_kernel failed", fn);
+    if (rc == IPX_OK) {
+        hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, st, ws.partial, bpi,
+                           (const uint32_t*)nullptr, hist_out_dev, lut);
+        if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "%s: launch of hist_finish_kernel failed", fn);
+    }
+    if (rc == IPX_OK)
+        rc = ipx_lut_dev_u8(stream, gray, dst, n, h, w, 1, gray_row_stride, gray_img_stride, dst_row_stride, dst_img_stride, lut, 256);
     if (own) {
         hipError_t e = hipFreeAsync(own, st);
         if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));

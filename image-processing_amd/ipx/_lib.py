@@ -37,6 +37,7 @@ SIGNATURES = {
     "ipx_hist_u8": (_i, [_vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _sz]),
     "ipx_equalize_lut_u8": (_i, [_vp, _vp, _i, _vp]),
     "ipx_equalize_hist_u8": (_i, _IMG + _STR + [_vp, _vp, _vp, _sz]),
+    "ipx_bgr2gray_equalize_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _sz]),
     "ipx_laplacian_sharpen_u8": (_i, _IMG + [_i] + _STR + [_vp, _vp]),
     "ipx_box3_u8": (_i, _IMG + [_i] + _STR + [_vp, _vp]),
     "ipx_sobel_u8": (_i, _IMG + [_i] + _STR + [_vp, _vp]),

@@ -149,13 +149,20 @@ def _gray(src: torch.Tensor) -> _Img:
     return s
 
 
+def _workspace(s: _Img) -> torch.Tensor:
+    """Scratch for the histogram kernels, from torch's caching allocator (stream-ordered, no hipMalloc per call)."""
+    nbytes = _lib.load().ipx_hist_workspace_bytes(s.n, s.h, s.w)
+    return torch.empty((nbytes,), dtype=torch.uint8, device=s.t.device)
+
+
 def hist(src: torch.Tensor) -> torch.Tensor:
     """256-bin histogram per image -> int32 tensor (N, 256) (or (256,) for a single H x W image).
     Counts are uint32 in the library; exposed as int32 because image sizes are capped at 2^31-1 pixels."""
     s = _gray(src)
     with torch.cuda.device(s.t.device):
         out = torch.empty((s.n, 256), dtype=torch.int32, device=s.t.device)
-        _lib.call("ipx_hist_u8", _stream(), s.ptr, s.n, s.h, s.w, s.row, s.img, out.data_ptr(), None, 0)
+        ws = _workspace(s)
+        _lib.call("ipx_hist_u8", _stream(), s.ptr, s.n, s.h, s.w, s.row, s.img, out.data_ptr(), ws.data_ptr(), ws.numel())
     return out[0] if src.ndim <= 3 else out
 
 
@@ -176,14 +183,36 @@ def equalize_hist(src: torch.Tensor, return_aux: bool = False):
     with torch.cuda.device(s.t.device):
         out = s.like()
         hst = lut = None
+        ws = _workspace(s)
         if return_aux:
             hst = torch.empty((s.n, 256), dtype=torch.int32, device=s.t.device)
             lut = torch.empty((s.n, 256), dtype=torch.uint8, device=s.t.device)
         _lib.call("ipx_equalize_hist_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w,
                   s.row, s.img, s.w, s.w * s.h,
-                  hst.data_ptr() if return_aux else None, lut.data_ptr() if return_aux else None, None, 0)
+                  hst.data_ptr() if return_aux else None, lut.data_ptr() if return_aux else None,
+                  ws.data_ptr(), ws.numel())
     res = s.restore(out)
     return (res, hst, lut) if return_aux else res
+
+
+def bgr2gray_equalize(src: torch.Tensor, return_aux: bool = False):
+    """server.py:245-246 on a colour image in one pass over the source: returns (gray, equalized[, hist, lut])."""
+    s = _Img(src)
+    if s.c not in (3, 4):
+        raise ValueError("bgr2gray_equalize needs 3 (BGR) or 4 (BGRA) channels")
+    with torch.cuda.device(s.t.device):
+        gray, out = s.like(1), s.like(1)
+        ws = torch.empty((_lib.load().ipx_hist_workspace_bytes(s.n, s.h, s.w),), dtype=torch.uint8, device=s.t.device)
+        hst = lut = None
+        if return_aux:
+            hst = torch.empty((s.n, 256), dtype=torch.int32, device=s.t.device)
+            lut = torch.empty((s.n, 256), dtype=torch.uint8, device=s.t.device)
+        _lib.call("ipx_bgr2gray_equalize_u8", _stream(), s.ptr, gray.data_ptr(), out.data_ptr(), s.n, s.h, s.w, s.c,
+                  s.row, s.img, s.w, s.w * s.h, s.w, s.w * s.h,
+                  hst.data_ptr() if return_aux else None, lut.data_ptr() if return_aux else None, ws.data_ptr(), ws.numel())
+    if src.ndim == 3:
+        gray, out = gray[0, :, :, 0], out[0, :, :, 0]
+    return (gray, out, hst, lut) if return_aux else (gray, out)
 
 
 # ---- convolutions --------------------------------------------------------------------------------

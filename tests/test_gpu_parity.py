@@ -73,6 +73,21 @@ def test_hist_and_equalize(dev, shape):
     np.testing.assert_array_equal(host(out), O.equalize_hist_u8(img))
 
 
+@pytest.mark.parametrize("shape", SHAPES + [(300, 411)])
+@pytest.mark.parametrize("cn", [3, 4])
+def test_bgr2gray_equalize_fused(dev, shape, cn):
+    img = rnd(shape + (cn,), 21)
+    gray, eq, h, lut = ops.bgr2gray_equalize(dev_t(img, dev), return_aux=True)
+    g = O.bgr2gray_u8(img)
+    np.testing.assert_array_equal(host(gray), g)
+    np.testing.assert_array_equal(host(h)[0].astype(np.uint32), O.hist_u8(g))
+    np.testing.assert_array_equal(host(eq), O.equalize_hist_u8(g))
+    imgs = rnd((3,) + shape + (cn,), 22)
+    gray, eq = ops.bgr2gray_equalize(dev_t(imgs, dev))
+    for i in range(3):
+        np.testing.assert_array_equal(host(eq)[i, :, :, 0], O.equalize_hist_u8(O.bgr2gray_u8(imgs[i])))
+
+
 def test_hist_distributions(dev):
     """all-one-bin (LDS contention worst case), low contrast, two-level, missing low bins."""
     rng = np.random.default_rng(7)
