@@ -1,0 +1,193 @@
+"""Flask host that keeps server.py's request/response contract and runs the pixel arithmetic on the GPU.
+
+Contract (server.py:19-29, 243-283, 358-388, 443-476; client side src/app.js:855-897, 1089-1140):
+  POST /api/process   multipart: file (required), mode (default 'gray8'), extras as strings
+  200 {'dataURL': 'data:image/png;base64,...', 'message': str, 'params': dict}
+  400 {'error': ...} for parameter errors, 500 {'error': str(e)} for any exception.
+Mode names, aliases, defaults, clamps, messages and params are the reference's.  Modes whose arithmetic is
+outside this build's scope (C10-C13) answer 501 with an explanatory error instead of
+silently running on the CPU; three extension modes ('gaussian', 'box', 'sobel') expose the remaining kernels.
+
+The arithmetic goes through a backend object with the ipx.ops surface.  The default (and only shipped) backend
+is the HIP library; tests inject a checker backend to exercise this dispatch logic on machines without a GPU.
+"""
+from __future__ import annotations
+
+import threading
+
+import numpy as np
+from flask import Flask, jsonify, request
+
+from . import codec, luts
+
+OUT_OF_SCOPE = ("pca_nn", "count_objects", "denoise_manual", "frequency_filter", "wiener", "median")
+
+
+class GpuBackend:
+    """numpy in / numpy out over ipx.ops on one GPU.  Each request runs on a per-thread HIP stream (Flask's
+    dev server handles requests on threads); libipx itself keeps no shared state."""
+
+    def __init__(self, device: str = "cuda:0"):
+        import torch
+        from . import _lib, ops
+        _lib.load()
+        self.torch, self.ops = torch, ops
+        self.device = torch.device(device)
+        with torch.cuda.device(self.device):
+            _lib.call("ipx_check_device")
+        self._tls = threading.local()
+
+    def _stream(self):
+        s = getattr(self._tls, "stream", None)
+        if s is None:
+            s = self._tls.stream = self.torch.cuda.Stream(device=self.device)
+        return s
+
+    def run(self, fn, *arrays):
+        """Stage arrays to the device, run fn(ops, *tensors) on this thread's stream, bring results back."""
+        torch = self.torch
+        with torch.cuda.device(self.device), torch.cuda.stream(self._stream()):
+            ts = [torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(self.device, non_blocking=True) for a in arrays]
+            out = fn(self.ops, *ts)
+            outs = out if isinstance(out, tuple) else (out,)
+            host = [o.to("cpu", non_blocking=False).numpy() if isinstance(o, torch.Tensor) else o for o in outs]
+        return host if isinstance(out, tuple) else host[0]
+
+
+def ensure_gray_uint8(backend, img_bytes: bytes) -> np.ndarray:
+    """server.py:492-531: decode, drop alpha, BGR->gray (GPU), 16-bit >> 8."""
+    img = codec.decode_unchanged(img_bytes)
+    if img.ndim == 3:
+        img = backend.run(lambda ops, t: ops.bgr2gray(t), img)          # 3 or 4 channels; alpha dropped
+    if img.dtype == np.uint16:
+        img = (img >> 8).astype(np.uint8)                                # server.py:521-523
+    if img.ndim != 2 or img.dtype != np.uint8:
+        raise RuntimeError("Cannot decode image to grayscale 8-bit. unknown error")
+    return img
+
+
+def create_app(backend=None) -> Flask:
+    app = Flask(__name__)
+    state = {"backend": backend}
+
+    def be():
+        if state["backend"] is None:
+            state["backend"] = GpuBackend()
+        return state["backend"]
+
+    @app.route("/api/process", methods=["POST"])
+    def api_process():
+        f = request.files.get("file")
+        mode = request.form.get("mode", "gray8")
+        if not f:
+            return jsonify({"error": "missing file"}), 400
+        try:
+            data = f.read()
+            params = {}
+            b = be()
+
+            if mode in OUT_OF_SCOPE:
+                return jsonify({"error": f"mode '{mode}' is outside the GPU hot path of this backend "
+                                         "(convolution filters, histogram equalization, pixel-wise transforms)"}), 501
+
+            if mode == "histogram_eq":                                  # server.py:243-248
+                img = codec.decode_unchanged(data)
+                if img.ndim == 3:                                        # colour: gray + histogram in one pass
+                    img_eq = b.run(lambda ops, t: ops.bgr2gray_equalize(t)[1], img)
+                else:
+                    if img.dtype == np.uint16:
+                        img = (img >> 8).astype(np.uint8)
+                    img_eq = b.run(lambda ops, t: ops.equalize_hist(t), img)
+                params = {"method": "Histogram Equalization"}
+                return jsonify({"dataURL": codec.to_data_url_png(img_eq), "message": "Histogram Equalized", "params": params}), 200
+
+            if mode == "sharpening":                                    # server.py:250-283
+                img = codec.decode_color(data)
+                if img is None:
+                    img = ensure_gray_uint8(b, data)
+                    is_color = False
+                else:
+                    is_color = True
+                sharp_type = request.form.get("sharp_type", "laplacian")
+                if sharp_type == "laplacian":
+                    img_sharp = b.run(lambda ops, t: ops.laplacian_sharpen(t), img)
+                    method = "Laplacian"
+                else:
+                    img_sharp = img
+                    method = "No sharpening"
+                params = {"method": method, "color": is_color}
+                return jsonify({"dataURL": codec.to_data_url_png(img_sharp), "message": f"Sharpened: {method}", "params": params}), 200
+
+            if mode == "pca":                                           # server.py:353-356
+                return jsonify({"error": "mode 'pca' has been removed on server. Use 'pca_nn' for PCA+NN inference "
+                                         "or 'detect' for object detection."}), 400
+
+            if mode in ("gaussian", "box", "sobel"):                    # extension modes (not in the reference)
+                img = codec.decode_unchanged(data)
+                if img.dtype == np.uint16:
+                    img = (img >> 8).astype(np.uint8)
+                if img.ndim == 3 and img.shape[2] == 4:
+                    img = np.ascontiguousarray(img[:, :, :3])
+                if mode == "gaussian":
+                    k = int(request.form.get("k", "5"))
+                    if k % 2 == 0:
+                        k += 1
+                    k = max(1, min(255, k))
+                    out = b.run(lambda ops, t: ops.gaussian_blur(t, k), img)
+                    params = {"ksize": k}
+                elif mode == "box":
+                    out = b.run(lambda ops, t: ops.box3(t), img)
+                else:
+                    out = b.run(lambda ops, t: ops.sobel(t), img)
+                return jsonify({"dataURL": codec.to_data_url_png(out), "message": "ok", "params": params}), 200
+
+            # every other mode works on grayscale (server.py:358-360); unknown modes return plain gray
+            lut = None
+            if mode in ("gamma", "powerlaw", "power-law"):              # server.py:362-373
+                gamma_param = request.form.get("gamma") or request.form.get("gamma_value") or request.form.get("g")
+                if gamma_param is None:
+                    return jsonify({"error": "Missing required parameter: gamma"}), 400
+                gamma_val = float(gamma_param)
+                lut = luts.gamma(gamma_val)
+                params = {"gamma": float(gamma_val)}
+            elif mode == "negative":                                    # server.py:375-376
+                lut = luts.negative()
+            elif mode == "threshold":                                   # server.py:378-381
+                T = int(request.form.get("threshold") or request.form.get("T") or 128)
+                lut = luts.threshold(T)
+                params["threshold"] = T
+            elif mode in ("piecewise", "piecewise_linear", "stretch"):  # server.py:443-469
+                if not all(k in request.form for k in ["r1", "s1", "r2", "s2"]):
+                    return jsonify({"error": "Missing required parameters: r1, s1, r2, s2"}), 400
+                r1, s1, r2, s2 = luts.piecewise_clamp(int(request.form.get("r1")), int(request.form.get("s1")),
+                                                      int(request.form.get("r2")), int(request.form.get("s2")))
+                lut = luts.piecewise(r1, s1, r2, s2)
+                params = {"r1": r1, "s1": s1, "r2": r2, "s2": s2}
+
+            img = codec.decode_unchanged(data)
+            is_log = mode in ("log", "logarithmic", "logrithmic")       # server.py:383-388
+            if is_log:
+                c_val = float(request.form.get("c", "2.0"))
+                gray = ensure_gray_uint8(b, data) if img.ndim == 3 or img.dtype != np.uint8 else img
+                hist = b.run(lambda ops, t: ops.hist(t), gray)           # s.max() needs the levels present
+                out = b.run(lambda ops, t: ops.apply_lut(t, luts.log(c_val, hist)), gray)
+            elif lut is not None and img.ndim == 3:
+                out = b.run(lambda ops, t: ops.bgr2gray_lut(t, lut), img)   # gray + table in one pass
+            else:
+                gray = ensure_gray_uint8(b, data) if img.ndim == 3 or img.dtype != np.uint8 else img
+                out = gray if lut is None else b.run(lambda ops, t: ops.apply_lut(t, lut), gray)
+            return jsonify({"dataURL": codec.to_data_url_png(out), "message": "ok", "params": params}), 200
+        except Exception as e:                                          # server.py:473-476
+            import traceback
+            traceback.print_exc()
+            return jsonify({"error": str(e)}), 500
+
+    return app
+
+
+def main():
+    create_app().run(host="0.0.0.0", port=5500, debug=False, threaded=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,175 @@
+"""Multi-GPU layer the reference does not have.
+
+* `BatchSharder`   -- a batch of independent images, image i -> GPU i mod G, one host thread, one HIP stream and
+                      pinned staging per GPU, host-side gather in input order.  No collective.  (server-side use)
+* `shard_range` / `gather_in_order` -- the same partition for one-process-per-GPU launches (torchrun); the
+                      gather is a host-side object gather, never a data-path collective.
+* `RowPartition`   -- ONE giant image split into contiguous row blocks over the ranks of a torch.distributed
+                      group (RCCL on GPUs): convolutions exchange r halo rows with the two neighbours
+                      (send/recv over xGMI), histogram equalization all-reduces the 256-bin histogram (1 KiB) and
+                      the log transform all-reduces it too (it needs the global set of levels).  LUT ops need nothing.
+
+The arithmetic goes through an `ops` object with the ipx.ops surface (default: the HIP library).
+"""
+from __future__ import annotations
+
+import threading
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> range:
+    """Images rank `rank` of `world` processes: i with i % world == rank (round-robin)."""
+    return range(rank, n, world)
+
+
+def gather_in_order(local: List, n: int, rank: int, world: int, group=None) -> Optional[List]:
+    """Host-side gather of per-rank result lists back into input order (rank 0 gets the list, others None)."""
+    import torch.distributed as dist
+    if world == 1:
+        return list(local)
+    bucket = [None] * world if rank == 0 else None
+    dist.gather_object(list(local), bucket, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = [None] * n
+    for r in range(world):
+        for j, i in enumerate(shard_range(n, r, world)):
+            out[i] = bucket[r][j]
+    return out
+
+
+class BatchSharder:
+    """map(images, fn): fn(ops, tensor) -> tensor | tuple of tensors, run on GPU (i mod G) for image i."""
+
+    def __init__(self, devices: Optional[Sequence[str]] = None, ops=None):
+        import torch
+        self.torch = torch
+        if devices is None:
+            devices = [f"cuda:{i}" for i in range(torch.cuda.device_count())]
+        if not devices:
+            raise RuntimeError("BatchSharder: no GPU visible (there is no CPU fallback)")
+        self.devices = [torch.device(d) for d in devices]
+        if ops is None:
+            from . import _lib, ops as _ops
+            _lib.load()
+            ops = _ops
+        self.ops = ops
+
+    def _worker(self, di: int, images, fn, out, errors):
+        torch = self.torch
+        dev = self.devices[di]
+        try:
+            cuda = dev.type == "cuda"
+            stream = torch.cuda.Stream(device=dev) if cuda else None
+            ctx = torch.cuda.stream(stream) if cuda else _Null()
+            with ctx:
+                pending = []
+                for i in range(di, len(images), len(self.devices)):
+                    a = np.ascontiguousarray(images[i])
+                    t = torch.from_numpy(a)
+                    t = t.pin_memory().to(dev, non_blocking=True) if cuda else t
+                    res = fn(self.ops, t)
+                    pending.append((i, res))
+                for i, res in pending:                              # copies back queue behind the kernels
+                    if isinstance(res, tuple):
+                        out[i] = tuple(r.to("cpu").numpy() for r in res)
+                    else:
+                        out[i] = res.to("cpu").numpy()
+                if cuda:
+                    stream.synchronize()
+        except BaseException as e:  # noqa: BLE001 - reported to the caller thread
+            errors.append((di, e))
+
+    def map(self, images: Sequence[np.ndarray], fn: Callable) -> List:
+        out: List = [None] * len(images)
+        errors: List = []
+        threads = [threading.Thread(target=self._worker, args=(d, images, fn, out, errors), daemon=True)
+                   for d in range(min(len(self.devices), max(1, len(images))))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise RuntimeError(f"BatchSharder: device {self.devices[errors[0][0]]} failed: {errors[0][1]!r}") from errors[0][1]
+        return out
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class RowPartition:
+    """Contiguous row block [y0, y1) of an H-row image on each rank of `group`."""
+
+    def __init__(self, height: int, rank: int, world: int, group=None, ops=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.h, self.rank, self.world, self.group = height, rank, world, group
+        base, rem = divmod(height, world)
+        self.y0 = rank * base + min(rank, rem)
+        self.y1 = self.y0 + base + (1 if rank < rem else 0)
+        self.min_rows = base                                          # every shard has at least this many rows
+        if ops is None:
+            from . import _lib, ops as _ops
+            _lib.load()
+            ops = _ops
+        self.ops = ops
+
+    def rows(self) -> slice:
+        return slice(self.y0, self.y1)
+
+    # -- halo exchange ------------------------------------------------------------------------------
+    def exchange_halo(self, local, r: int):
+        """Send my first/last r rows to the upper/lower neighbour and receive theirs.  Returns (top, bottom);
+        None where the shard touches the image border (REFLECT_101 is applied locally there)."""
+        torch, dist = self.torch, self.dist
+        if r == 0 or self.world == 1:
+            return None, None
+        if self.min_rows < r:
+            raise ValueError(f"row shards of {self.min_rows} rows are shorter than the halo radius {r}")
+        up, down = self.rank - 1, self.rank + 1
+        top = torch.empty_like(local[:r]) if up >= 0 else None
+        bot = torch.empty_like(local[:r]) if down < self.world else None
+        ops_ = []
+        if up >= 0:
+            ops_.append(dist.P2POp(dist.isend, local[:r].contiguous(), up, group=self.group))
+            ops_.append(dist.P2POp(dist.irecv, top, up, group=self.group))
+        if down < self.world:
+            ops_.append(dist.P2POp(dist.isend, local[-r:].contiguous(), down, group=self.group))
+            ops_.append(dist.P2POp(dist.irecv, bot, down, group=self.group))
+        for w in dist.batch_isend_irecv(ops_):
+            w.wait()
+        return top, bot
+
+    def conv3(self, local, name: str):
+        """name in {'laplacian_sharpen', 'box3', 'sobel'}."""
+        top, bot = self.exchange_halo(local, 1)
+        return getattr(self.ops, name)(local, top_halo=top, bottom_halo=bot)
+
+    def gaussian_blur(self, local, k: int):
+        top, bot = self.exchange_halo(local, k // 2)
+        return self.ops.gaussian_blur(local, k, top_halo=top, bottom_halo=bot)
+
+    # -- global histogram -----------------------------------------------------------------------------
+    def global_hist(self, local):
+        h = self.ops.hist(local).reshape(256).contiguous()
+        if self.world > 1:
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+        return h
+
+    def equalize_hist(self, local):
+        """Local 256-bin histogram -> all-reduce(sum) of 1 KiB -> identical table on every rank -> local apply."""
+        lut = self.ops.equalize_lut(self.global_hist(local))
+        return self.ops.apply_lut_dev(local, lut)
+
+    def log_transform(self, local, c: float = 2.0):
+        from . import luts
+        present = self.global_hist(local).cpu().numpy()
+        return self.ops.apply_lut(local, luts.log(c, present))

@@ -1,0 +1,85 @@
+"""world_size-2/3 gloo tests (CPU) of the multi-GPU host logic: row partition with halo exchange, global
+histogram all-reduce, log transform's global level set, and the ordered host-side gather of a sharded batch.
+The per-shard arithmetic is the test-only oracle backend; the collectives and the partition logic are the
+product's (ipx/sharder.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, H, ret):
+    for p in (os.path.join(ROOT, "image-processing_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from oracle_ops import OracleOps
+        from ipx.sharder import RowPartition, gather_in_order, shard_range
+        rng = np.random.default_rng(42)
+        gray = np.clip(rng.normal(110, 40, (H, 96)), 0, 250).astype(np.uint8)       # max < 255 for the log case
+        gray[H // 2:, :] = np.minimum(gray[H // 2:, :], 180)                          # global max lives in the top half
+        bgr = rng.integers(0, 256, (H, 64, 3), dtype=np.uint8)
+        part = RowPartition(H, rank, world, ops=OracleOps)
+        assert part.y1 - part.y0 >= H // world
+        lg, lb = torch.from_numpy(gray[part.rows()].copy()), torch.from_numpy(bgr[part.rows()].copy())
+        checks = {
+            "equalize": (part.equalize_hist(lg).numpy(), O.equalize_hist_u8(gray)[part.rows()]),
+            "log": (part.log_transform(lg, 2.0).numpy(), O.log_u8(gray, 2.0)[part.rows()]),
+            "sharpen": (part.conv3(lb, "laplacian_sharpen").numpy(), O.laplacian_sharpen_u8(bgr)[part.rows()]),
+            "sobel": (part.conv3(lg, "sobel").numpy(), O.sobel_u8(gray)[part.rows()]),
+            "box": (part.conv3(lg, "box3").numpy(), O.box3_u8(gray)[part.rows()]),
+            "gauss5": (part.gaussian_blur(lb, 5).numpy(), O.gaussian_blur_u8(bgr, 5)[part.rows()]),
+            "gauss15": (part.gaussian_blur(lg, 15).numpy(), O.gaussian_blur_u8(gray, 15)[part.rows()]),
+        }
+        bad = [k for k, (a, b) in checks.items() if not np.array_equal(a, b)]
+        # global histogram is the whole image's on every rank
+        gh = part.global_hist(lg).numpy()
+        if not np.array_equal(gh.astype(np.uint32), O.hist_u8(gray)):
+            bad.append("global_hist")
+        # sharded batch: rank r handles images r, r+world, ...; rank 0 gathers in input order
+        n = 7
+        local = [f"img{i}@rank{rank}" for i in shard_range(n, rank, world)]
+        got = gather_in_order(local, n, rank, world)
+        if rank == 0 and got != [f"img{i}@rank{i % world}" for i in range(n)]:
+            bad.append("gather_in_order")
+        if rank != 0 and got is not None:
+            bad.append("gather_nonroot")
+        ret[rank] = bad
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H", [(2, 64), (3, 50)])
+def test_row_partition_and_gather(world, H):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, H, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: [] for r in range(world)}
+
+
+def test_halo_radius_larger_than_shard_is_rejected():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_ops import OracleOps
+    from ipx.sharder import RowPartition
+    part = RowPartition(8, 0, 4, ops=OracleOps)
+    part.world = 4
+    with pytest.raises(ValueError, match="shorter than the halo radius"):
+        part.exchange_halo(torch.zeros((2, 4), dtype=torch.uint8), 3)

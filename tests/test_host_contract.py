@@ -1,0 +1,148 @@
+"""CPU suite for the host side: server.py's HTTP contract (statuses, keys, messages, params, aliases, clamps)
+replayed against tests/golden/server_contract.json, the batch sharder's ordering, and codec round trips.
+The arithmetic behind the dispatch is the test-only oracle backend here; tests/test_gpu_host.py repeats the
+contract run with the real GPU backend."""
+import io
+import json
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import ipx.app as app_mod
+import ipx.codec as codec
+from ipx.sharder import BatchSharder, shard_range
+from oracle_ops import OracleBackend, OracleOps
+import oracle as O
+
+
+def png(a):
+    buf = io.BytesIO()
+    Image.fromarray(a).save(buf, format="PNG")
+    return buf.getvalue()
+
+
+def post(client, img, mode, **form):
+    data = {k: str(v) for k, v in form.items()}
+    if mode is not None:
+        data["mode"] = mode
+    if img is not None:
+        data["file"] = (io.BytesIO(png(img)), "x.png")
+    r = client.post("/api/process", data=data, content_type="multipart/form-data")
+    return r.status_code, r.get_json()
+
+
+@pytest.fixture(scope="module")
+def client():
+    return app_mod.create_app(backend=OracleBackend()).test_client()
+
+
+def replay_contract(client, golden):
+    g, meta = golden
+    n = 0
+    for c in meta["cases"]:
+        img = g["in_" + c["input"]] if c["input"] else None
+        st, js = post(client, img, c["mode"], **c["form"])
+        assert st == c["status"], c["name"]
+        if st == 200:
+            assert set(js) == {"dataURL", "message", "params"}
+            assert js["message"] == c["message"], c["name"]
+            assert js["params"] == c["params"], c["name"]
+            np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), g["out_" + c["name"]], err_msg=c["name"])
+        else:
+            assert js == {"error": c["error"]}, c["name"]
+        n += 1
+    return n
+
+
+def test_contract_replay_matches_real_server(client, golden):
+    assert replay_contract(client, golden) >= 70
+
+
+def test_opencv_backed_modes_contract(client):
+    rng = np.random.default_rng(0)
+    gray = rng.integers(0, 256, (40, 52), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (40, 52, 3), dtype=np.uint8)
+    bgr = rgb[:, :, ::-1]
+    st, js = post(client, gray, "histogram_eq")
+    assert st == 200 and js["message"] == "Histogram Equalized" and js["params"] == {"method": "Histogram Equalization"}
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.equalize_hist_u8(gray))
+    st, js = post(client, rgb, "histogram_eq")                       # colour input -> gray first (server.py:245)
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.equalize_hist_u8(O.bgr2gray_u8(bgr)))
+    st, js = post(client, rgb, "sharpening")
+    assert st == 200 and js["message"] == "Sharpened: Laplacian" and js["params"] == {"method": "Laplacian", "color": True}
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.laplacian_sharpen_u8(bgr))
+    st, js = post(client, gray, "sharpening")                        # IMREAD_COLOR makes gray 3-channel (server.py:252)
+    assert js["params"]["color"] is True
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.laplacian_sharpen_u8(np.repeat(gray[:, :, None], 3, 2)))
+    st, js = post(client, rgb, "sharpening", sharp_type="other")
+    assert js["message"] == "Sharpened: No sharpening" and js["params"]["method"] == "No sharpening"
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), bgr)
+    for T, key in ((128, "threshold"), (0, "T"), (-3, "threshold"), (255, "T"), (300, "threshold")):
+        st, js = post(client, gray, "threshold", **{key: T})
+        assert st == 200 and js["params"] == {"threshold": T} and js["message"] == "ok"
+        np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.threshold_u8(gray, T))
+    st, js = post(client, gray, "threshold")                         # default 128 (server.py:379)
+    assert js["params"] == {"threshold": 128}
+    st, js = post(client, gray, "threshold", threshold="abc")        # int('abc') -> 500 with the exception text
+    assert st == 500 and "invalid literal" in js["error"]
+    st, js = post(client, rgb, "gray8")
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.bgr2gray_u8(bgr))
+    st, js = post(client, rgb, "gamma", gamma=0.6)                   # fused gray + table
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.gamma_u8(O.bgr2gray_u8(bgr), 0.6))
+    st, js = post(client, rgb, "log", c=2.0)
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.log_u8(O.bgr2gray_u8(bgr), 2.0))
+
+
+def test_out_of_scope_modes_say_so(client):
+    gray = np.zeros((8, 8), np.uint8)
+    for mode in app_mod.OUT_OF_SCOPE:
+        st, js = post(client, gray, mode)
+        assert st == 501 and "outside the GPU hot path" in js["error"]
+    r = client.post("/api/process", data={"mode": "gray8", "file": (io.BytesIO(b"not an image"), "x.png")},
+                    content_type="multipart/form-data")
+    assert r.status_code == 500 and "Cannot decode image" in r.get_json()["error"]
+
+
+def test_extension_modes(client):
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (30, 44, 3), dtype=np.uint8)
+    bgr = rgb[:, :, ::-1]
+    st, js = post(client, rgb, "gaussian", k=4)                       # even -> next odd, as server.py:406-407 does
+    assert st == 200 and js["params"] == {"ksize": 5}
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.gaussian_blur_u8(bgr, 5))
+    st, js = post(client, rgb, "box")
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.box3_u8(bgr))
+
+
+def test_codec_alpha_16bit_palette():
+    rng = np.random.default_rng(2)
+    rgba = rng.integers(0, 256, (9, 11, 4), dtype=np.uint8)
+    a = codec.decode_unchanged(png(rgba))
+    assert a.shape == (9, 11, 4)
+    np.testing.assert_array_equal(a[..., :3], rgba[..., 2::-1])
+    g16 = rng.integers(0, 65536, (9, 11), dtype=np.uint16)
+    buf = io.BytesIO(); Image.fromarray(g16).save(buf, format="PNG")
+    d = codec.decode_unchanged(buf.getvalue())
+    assert d.dtype == np.uint16
+    np.testing.assert_array_equal(d, g16)
+    np.testing.assert_array_equal(codec.decode_color(buf.getvalue())[..., 0], (g16 >> 8).astype(np.uint8))
+    np.testing.assert_array_equal(app_mod.ensure_gray_uint8(OracleBackend(), buf.getvalue()), (g16 >> 8).astype(np.uint8))
+    np.testing.assert_array_equal(app_mod.ensure_gray_uint8(OracleBackend(), png(rgba)), O.bgr2gray_u8(rgba[..., [2, 1, 0, 3]]))
+    bgr = rng.integers(0, 256, (5, 6, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(codec.from_data_url_png(codec.to_data_url_png(bgr)), bgr)
+
+
+def test_batch_sharder_order_and_round_robin():
+    rng = np.random.default_rng(3)
+    imgs = [rng.integers(0, 256, (10 + i, 12, 3), dtype=np.uint8) for i in range(7)]
+    sh = BatchSharder(devices=["cpu", "cpu", "cpu"], ops=OracleOps)
+    outs = sh.map(imgs, lambda ops, t: ops.laplacian_sharpen(t))
+    for i, o in enumerate(outs):
+        np.testing.assert_array_equal(o, O.laplacian_sharpen_u8(imgs[i]))
+    outs = sh.map(imgs, lambda ops, t: ops.bgr2gray_equalize(t))
+    for i, (g, e) in enumerate(outs):
+        np.testing.assert_array_equal(e, O.equalize_hist_u8(O.bgr2gray_u8(imgs[i])))
+    assert list(shard_range(7, 1, 3)) == [1, 4] and list(shard_range(2, 3, 4)) == []
+    with pytest.raises(RuntimeError, match="failed"):
+        sh.map(imgs, lambda ops, t: ops.nonexistent(t))
