@@ -15,6 +15,9 @@
 // image, column pass back to uint8).
 #include "ipx_common.h"
 #include <stdlib.h>
+#ifndef IPX_ABLATE
+#define IPX_ABLATE 0
+#endif
 #ifndef IPX_CONV_NT_LOADS
 #define IPX_CONV_NT_LOADS 0
 #endif
@@ -22,8 +25,7 @@
 
 namespace {
 
-constexpr int kWavesPerBlock = 4;
-constexpr int kThreads = 64 * kWavesPerBlock;
+constexpr int kMaxWavesPerBlock = 16;
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef short ss2 __attribute__((ext_vector_type(2)));
@@ -33,7 +35,7 @@ struct ConvGeom {
     int64_t s_row, s_img, d_row, d_img;
     int nlanes;                        // 16-byte lanes of the main region: bytes [16, 16 + 16*nlanes)
     int lanes_per_strip, nstrips, seg_rows, nsegs;
-    unsigned nitems;                   // n * nsegs * nstrips wave work items
+    int wpb, blocks_per_seg;           // waves per block, blocks per (image, segment)
     unsigned main_blocks;              // blocks [0, main_blocks) walk strips, the rest do border bytes
     int nb;                            // border bytes per row: [0,16) and [16 + 16*nlanes, L)  (or all of L)
     unsigned border_total;             // n * h * nb
@@ -66,8 +68,13 @@ __device__ __forceinline__ void load_win(Win<C, R>& W, const uint8_t* rp, int b0
 #else
     __builtin_memcpy(&W.w[HD], rp + b0, 16);
 #endif
+#if IPX_ABLATE & 1          // dev ablation: no halo loads (results are wrong; timing only)
+#pragma unroll
+    for (int i = 0; i < HD; ++i) { W.w[i] = W.w[HD + i]; W.w[HD + 4 + i] = W.w[HD + 3 - i]; }
+#else
     __builtin_memcpy(&W.w[0], rp + b0 - 4 * HD, 4 * HD);
     __builtin_memcpy(&W.w[HD + 4], rp + b0 + 16, 4 * HD);
+#endif
 }
 
 // Field pair (byte p, byte p+2) of the window, zero-extended to 2 x u16; p is relative to b0 and static.
@@ -227,7 +234,7 @@ __device__ __forceinline__ uint32_t conv3_byte(const uint8_t* r0, const uint8_t*
 // Decode a border thread: false if out of range.  b = byte in the row, y = row, img.
 __device__ __forceinline__ bool border_item(const ConvGeom& g, unsigned bblock, unsigned& img, int& y, int& b)
 {
-    const unsigned t = bblock * kThreads + threadIdx.x;
+    const unsigned t = bblock * blockDim.x + threadIdx.x;
     if (t >= g.border_total) return false;
     const unsigned j = t % (unsigned)g.nb, rest = t / (unsigned)g.nb;
     y = (int)(rest % (unsigned)g.h);
@@ -236,14 +243,16 @@ __device__ __forceinline__ bool border_item(const ConvGeom& g, unsigned bblock, 
     return true;
 }
 
-// Decode the wave's strip item; all values wave-uniform (SGPRs).
+// Decode the wave's strip item; all values wave-uniform (SGPRs).  A block of wpb = blockDim.x / 64 waves covers wpb
+// ADJACENT strips of one row segment, so that a block streams a wide contiguous span of every row it walks.
 __device__ __forceinline__ bool wave_item(const ConvGeom& g, unsigned& img, int& y0, int& y1, int& lane0)
 {
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned item = xcd_remap(blockIdx.x, g.main_blocks) * kWavesPerBlock + wave;
-    if (item >= g.nitems) return false;
-    const unsigned strip = item % (unsigned)g.nstrips;
-    const unsigned rest = item / (unsigned)g.nstrips;
+    const unsigned blk = xcd_remap(blockIdx.x, g.main_blocks);
+    const unsigned sub = blk % (unsigned)g.blocks_per_seg;
+    const unsigned rest = blk / (unsigned)g.blocks_per_seg;
+    const unsigned strip = sub * (unsigned)g.wpb + wave;
+    if (strip >= (unsigned)g.nstrips) return false;
     const unsigned seg = rest % (unsigned)g.nsegs;
     img = rest / (unsigned)g.nsegs;
     y0 = (int)seg * g.seg_rows;
@@ -253,7 +262,7 @@ __device__ __forceinline__ bool wave_item(const ConvGeom& g, unsigned& img, int&
 }
 
 template <int OP, int C>
-__global__ __launch_bounds__(kThreads) void conv3_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+__global__ __launch_bounds__(64 * kMaxWavesPerBlock) void conv3_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                          ConvGeom g)
 {
     if (blockIdx.x >= g.main_blocks) {                       // ---- border bytes, one per thread
@@ -277,29 +286,33 @@ __global__ __launch_bounds__(kThreads) void conv3_kernel(const uint8_t* __restri
     typedef Conv3<OP, C> Op;
     constexpr int U = 4;                                     // rows per step; loads run one step ahead
 
+    // (Walking odd segments upwards so that neighbours meet at their shared halo rows was tried: no gain, removed.)
+    const int nrows = y1 - y0;
+    constexpr int dir = 1;
+    const int ys = y0;                                       // first output row
+    auto row = [&](int t) {                                  // t-th source row of the walk, t = 0 .. nrows + 1
+        return row_ptr(g, simg, ys + dir * ((t <= nrows + 1 ? t : nrows + 1) - 1), 1);
+    };
     typename Op::Feat fa, fb;
     {
         W1 wa, wb;
-        load_win<C, 1>(wa, row_ptr(g, simg, y0 - 1, 1), b0);
-        load_win<C, 1>(wb, row_ptr(g, simg, y0, 1), b0);
+        load_win<C, 1>(wa, row(0), b0);
+        load_win<C, 1>(wb, row(1), b0);
         Op::feat(fa, wa);
         Op::feat(fb, wb);
     }
     W1 nx[U];
 #pragma unroll
-    for (int j = 0; j < U; ++j) load_win<C, 1>(nx[j], row_ptr(g, simg, y0 + 1 + j <= y1 ? y0 + 1 + j : y1, 1), b0);
-    for (int y = y0; y < y1; y += U) {
+    for (int j = 0; j < U; ++j) load_win<C, 1>(nx[j], row(2 + j), b0);
+    for (int i = 0; i < nrows; i += U) {
         W1 nn[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) {                        // next step's rows (rows past the segment: re-read y1)
-            const int yy = y + U + 1 + j;
-            load_win<C, 1>(nn[j], row_ptr(g, simg, yy <= y1 ? yy : y1, 1), b0);
-        }
+        for (int j = 0; j < U; ++j) load_win<C, 1>(nn[j], row(i + U + 2 + j), b0);   // next step's rows
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             typename Op::Feat fc;
             Op::feat(fc, nx[j]);
-            if (y + j < y1) st16_nt(dimg + (int64_t)(y + j) * g.d_row + b0, Op::out(fa, fb, fc));
+            if (i + j < nrows) st16_nt(dimg + (int64_t)(ys + dir * (i + j)) * g.d_row + b0, Op::out(fa, fb, fc));
             fa = fb;
             fb = fc;
         }
@@ -325,7 +338,7 @@ __device__ __forceinline__ void hpass(us2 (&h)[8], const Win<C, K / 2>& W, const
 }
 
 template <int C, int K>
-__global__ __launch_bounds__(kThreads) void sep_small_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+__global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_small_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                              ConvGeom g, Taps<K> t)
 {
     constexpr int R = K / 2;
@@ -358,27 +371,38 @@ __global__ __launch_bounds__(kThreads) void sep_small_kernel(const uint8_t* __re
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     typedef Win<C, R> WR;
 
+    const int nrows = y1 - y0;
+    constexpr int dir = 1;
+    const int ys = y0;
+    const int tlast = nrows - 1 + 2 * R;                     // last source row of the walk anybody needs
+    auto row = [&](int tt) { return row_ptr(g, simg, ys + dir * ((tt <= tlast ? tt : tlast) - R), R); };
+
     us2 hw[K][8];                                            // ring of K row-pass results (statically indexed)
 #pragma unroll
-    for (int s = 0; s < K - 1; ++s) {                        // prologue: rows y0-R .. y0+R-1
+    for (int s = 0; s < K - 1; ++s) {                        // prologue: walk rows 0 .. K-2
         WR W;
-        load_win<C, R>(W, row_ptr(g, simg, y0 - R + s, R), b0);
+        load_win<C, R>(W, row(s), b0);
         hpass<C, K>(hw[s], W, t);
     }
-    const int ylast = y1 - 1 + R;                            // last source row anybody needs
     WR nx[K];
 #pragma unroll
-    for (int s = 0; s < K; ++s) load_win<C, R>(nx[s], row_ptr(g, simg, y0 + s + R <= ylast ? y0 + s + R : ylast, R), b0);
-    for (int y = y0; y < y1; y += K) {
+    for (int s = 0; s < K; ++s) load_win<C, R>(nx[s], row(K - 1 + s), b0);
+    for (int i0 = 0; i0 < nrows; i0 += K) {
 #pragma unroll
         for (int s = 0; s < K; ++s) {
+#if IPX_ABLATE & 2          // dev ablation: almost no arithmetic
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hw[(K - 1 + s) % K][q] = __builtin_bit_cast(us2, nx[s].w[(q & 3) + Win<C, R>::HD]);
+#else
             hpass<C, K>(hw[(K - 1 + s) % K], nx[s], t);
-            {                                                 // refill the slot just consumed: row y + K + s + R
-                const int yy = y + K + s + R;
-                load_win<C, R>(nx[s], row_ptr(g, simg, yy <= ylast ? yy : ylast, R), b0);
-            }
-            if (y + s < y1) {
+#endif
+            load_win<C, R>(nx[s], row(i0 + 2 * K - 1 + s), b0);   // refill the slot just consumed
+            if (i0 + s < nrows) {
                 u32x4 o;
+#if IPX_ABLATE & 2
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = __builtin_bit_cast(uint32_t, hw[s % K][k]) ^ __builtin_bit_cast(uint32_t, hw[(s + K - 1) % K][k + 4]);
+#else
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     uint32_t lo[2], hi[2];
@@ -396,7 +420,8 @@ __global__ __launch_bounds__(kThreads) void sep_small_kernel(const uint8_t* __re
                     }
                     o[k] = pack_acc(lo[0], lo[1], hi[0], hi[1]);
                 }
-                st16_nt(dimg + (int64_t)(y + s) * g.d_row + b0, o);
+#endif
+                st16_nt(dimg + (int64_t)(ys + dir * (i0 + s)) * g.d_row + b0, o);
             }
         }
     }
@@ -452,7 +477,7 @@ int env_int(const char* name, int dflt)
 }
 
 // hd4 = 4 * ceil(r*c/4): halo bytes a main-region lane reads on either side (<= 16)
-int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c, int r,
+int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c, int r, int max_wpb,
                    int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
                    const uint8_t* top, const uint8_t* bot)
 {
@@ -480,25 +505,31 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
     if (seg > h) seg = h;
     g.seg_rows = seg;
     g.nsegs = (h + seg - 1) / seg;
-    const uint64_t items = (uint64_t)n * g.nsegs * g.nstrips;
+    // waves per block: the strips of one row segment split evenly over as few blocks as max_wpb allows
+    int want = env_int("IPX_WPB", 0);
+    if (want <= 0) want = 4;
+    if (want > max_wpb) want = max_wpb;
+    g.blocks_per_seg = g.nstrips ? (g.nstrips + want - 1) / want : 1;
+    g.wpb = g.nstrips ? (g.nstrips + g.blocks_per_seg - 1) / g.blocks_per_seg : 1;
+    const uint64_t blocks = (uint64_t)n * g.nsegs * (g.nstrips ? g.blocks_per_seg : 0);
     g.nb = g.nlanes > 0 ? 16 + (g.L - 16 - 16 * g.nlanes) : g.L;
     const uint64_t btotal = (uint64_t)n * h * g.nb;
-    if (items > 0x3fffffffull || btotal > 0xffffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many work items", fn);
-    g.nitems = (unsigned)items;
-    g.main_blocks = (unsigned)((items + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (blocks > 0x3fffffffull || btotal > 0xffffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many work items", fn);
+    g.main_blocks = (unsigned)blocks;
     g.border_total = (unsigned)btotal;
     return IPX_OK;
 }
 
-unsigned conv_grid(const ConvGeom& g) { return g.main_blocks + (g.border_total + kThreads - 1) / kThreads; }
+unsigned conv_block(const ConvGeom& g) { return 64u * (unsigned)g.wpb; }
+unsigned conv_grid(const ConvGeom& g) { return g.main_blocks + (g.border_total + conv_block(g) - 1) / conv_block(g); }
 
 template <int OP>
 int launch_conv3(const char* fn, void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
                  int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* top, const uint8_t* bot)
 {
     ConvGeom g;
-    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, 1, s_row, s_img, d_row, d_img, top, bot)) return rc;
-    const dim3 grid(conv_grid(g)), block(kThreads);
+    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, 1, kMaxWavesPerBlock, s_row, s_img, d_row, d_img, top, bot)) return rc;
+    const dim3 grid(conv_grid(g)), block(conv_block(g));
     hipStream_t st = (hipStream_t)stream;
     switch (c) {
         case 1: hipLaunchKernelGGL((conv3_kernel<OP, 1>), grid, block, 0, st, src, dst, g); break;
@@ -516,7 +547,7 @@ void launch_sep_small(hipStream_t st, const uint8_t* src, uint8_t* dst, const Co
 {
     Taps<K> t;
     for (int i = 0; i < K; ++i) { t.kx[i] = kx[i]; t.ky[i] = ky[i]; }
-    hipLaunchKernelGGL((sep_small_kernel<C, K>), dim3(conv_grid(g)), dim3(kThreads), 0, st, src, dst, g, t);
+    hipLaunchKernelGGL((sep_small_kernel<C, K>), dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g, t);
 }
 
 template <int K>
@@ -567,7 +598,7 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     if (!kx_q8 || !ky_q8) return ipx_fail(IPX_ERR_INVALID, "%s: null taps", fn);
     if (k < 1 || (k & 1) == 0 || k > IPX_MAX_GAUSS_K) return ipx_fail(IPX_ERR_INVALID, "%s: k=%d must be odd and in 1..%d", fn, k, IPX_MAX_GAUSS_K);
     ConvGeom g;
-    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, k / 2, s_row, s_img, d_row, d_img, top_halo, bottom_halo)) return rc;
+    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, k / 2, k <= 5 ? kMaxWavesPerBlock : 8, s_row, s_img, d_row, d_img, top_halo, bottom_halo)) return rc;
     unsigned sx = 0, sy = 0;
     for (int i = 0; i < k; ++i) {
         if (kx_q8[i] > 256 || ky_q8[i] > 256) return ipx_fail(IPX_ERR_INVALID, "%s: tap %d exceeds 256 (Q0.8 of 1.0)", fn, i);

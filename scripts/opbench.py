@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--seg", default="0,16,24,32,48,64,96,128")
     ap.add_argument("--what", default="conv,eq,point")
+    ap.add_argument("--wpb", default="0")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B = a.batch
@@ -34,12 +35,13 @@ def main():
         ops.laplacian_sharpen(bgr); torch.cuda.synchronize()
     def rep(name, bpp, fn, extra=""):
         s = time_op(fn)
-        print(f"{name:28s} {extra:12s} {s*1e6:9.1f} us  {px*bpp/s/1e9:8.1f} GB/s  {px*bpp/s/8e12*100:5.1f}% of 8TB/s", flush=True)
+        print(f"{name:28s} {extra:16s} {s*1e6:9.1f} us  {px*bpp/s/1e9:8.1f} GB/s  {px*bpp/s/8e12*100:5.1f}% of 8TB/s", flush=True)
     what = a.what.split(",")
     if "conv" in what:
-        for seg in [int(x) for x in a.seg.split(",")]:
+        for seg, wpb in [(int(x), int(w)) for x in a.seg.split(",") for w in a.wpb.split(",")]:
             os.environ["IPX_SEG_ROWS"] = str(seg)
-            e = f"seg={seg}"
+            os.environ["IPX_WPB"] = str(wpb)
+            e = f"seg={seg} wpb={wpb}"
             rep("sharpen_bgr", 6, lambda: ops.laplacian_sharpen(bgr), e)
             rep("sobel_gray", 2, lambda: ops.sobel(gray), e)
             rep("box3_gray", 2, lambda: ops.box3(gray), e)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn a gpurun_out/<tag>/ directory written by scripts/collect_profiles.sh into committed summaries:
+profiles/<name>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), profiles/<name>_pmc.md (per-kernel HBM-side
+traffic from FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes: both in KiB, FETCH_SIZE x2 on
+gfx950 for wide coalesced reads), profiles/<name>_bench.json and profiles/pmc_traffic.json (read by bench.py).
+usage: python scripts/summarize_profiles.py gpurun_out/prof_r01_c r01"""
+import collections, csv, glob, json, os, re, shutil, sys
+
+src, name = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    return re.sub(r"\(.*", "", n).replace("void ", "").strip()
+
+shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0], os.path.join(out, f"{name}_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(out, f"{name}_bench.json"))
+stats = {short(r["Name"]): r for r in csv.DictReader(open(os.path.join(out, f"{name}_kernel_stats.csv")))}
+pmc = collections.defaultdict(dict)
+for which, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    vals = collections.defaultdict(list)
+    for r in csv.DictReader(open(glob.glob(os.path.join(src, which, "*", "*counter_collection.csv"))[0])):
+        if r["Counter_Name"] == ctr:
+            vals[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in vals.items():
+        pmc[k][ctr] = sum(v) / len(v)
+bench = json.load(open(os.path.join(src, "bench.json")))
+B = bench["config"]["batch_per_gpu"]
+px = B * 2160 * 3840
+alg = {"sep_small_kernel<3, 5>": 6, "conv3_kernel<2, 1>": 2, "conv3_kernel<0, 3>": 6, "gray_hist_kernel<3, false>": 4,
+       "gray_kernel<3, false, false>": 4, "lut_kernel<false, false>": 2, "lut_kernel<true, false>": 2,
+       "hist_partial_kernel<false>": 1}
+lines = [f"# {name}: per-kernel duration and HBM-side traffic (batch {B} x 3840x2160)", "",
+         "Source: `rocprofv3 --kernel-trace --stats` and two `--pmc` passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py`,",
+         "collected by scripts/collect_profiles.sh.  Counters are KiB; FETCH_SIZE is doubled (gfx950 reports half the bytes of a",
+         "wide coalesced stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE is taken as is.  `alg` = algorithmic bytes per launch.", "",
+         "| kernel | avg us | read MB (2 x FETCH_SIZE) | write MB | traffic MB | alg MB | traffic/alg | alg GB/s | frac of 8 TB/s |",
+         "|---|---|---|---|---|---|---|---|---|"]
+traffic_json = {}
+for k, c in sorted(pmc.items()):
+    if k not in stats or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        continue
+    us = float(stats[k]["AverageNs"]) / 1e3
+    rd, wr = 2 * c["FETCH_SIZE"] * 1024 / 1e6, c["WRITE_SIZE"] * 1024 / 1e6
+    a = alg.get(k)
+    amb = px * a / 1e6 if a else None
+    lines.append(f"| `{k}` | {us:.1f} | {rd:.1f} | {wr:.1f} | {rd + wr:.1f} | " +
+                 (f"{amb:.1f} | {(rd + wr) / amb:.3f} | {amb / us * 1e3:.0f} | {amb / us * 1e3 / 8000:.3f} |" if a else "- | - | - | - |"))
+    traffic_json[k] = int((rd + wr) * 1e6)
+open(os.path.join(out, f"{name}_pmc.md"), "w").write("\n".join(lines) + "\n")
+json.dump({"gaussian5_bgr": traffic_json.get("sep_small_kernel<3, 5>"), "per_kernel_bytes": traffic_json,
+           "source": f"profiles/{name}_pmc.md"}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+print("\n".join(lines))
