@@ -11,24 +11,21 @@
 // ragged tail behind the last full lane are computed by "border" blocks appended to the same launch with plain
 // per-byte code (REFLECT_101 in pixel space).  Tiny images are all border.
 // Neighbouring strips are consecutive work items and the block->item map is XCD-aware so that they share an L2.
-// Kernels larger than 7 taps go through the generic two-pass path at the bottom (row pass to a Q8.8 scratch
-// image, column pass back to uint8).
+// 9..31 taps: ipx_sepbig.hip (row-pass kernel + column-pass kernel around a Q8.8 scratch image).  Anything larger
+// (and k = 1) goes through the simple generic two-pass path at the bottom of this file.
 #include "ipx_common.h"
+#include "ipx_fields.h"
 #include <stdlib.h>
-#ifndef IPX_ABLATE
-#define IPX_ABLATE 0
-#endif
-#ifndef IPX_CONV_NT_LOADS
-#define IPX_CONV_NT_LOADS 0
-#endif
 #include <vector>
+
+int ipx_sep_mid(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+                int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
+                const uint16_t* kx, const uint16_t* ky, int k, const uint8_t* top, const uint8_t* bot);
 
 namespace {
 
 constexpr int kMaxWavesPerBlock = 16;
 
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-typedef short ss2 __attribute__((ext_vector_type(2)));
 
 struct ConvGeom {
     int h, w, L;                       // rows, pixels per row, bytes per row
@@ -49,78 +46,6 @@ __device__ __forceinline__ const uint8_t* row_ptr(const ConvGeom& g, const uint8
     if (y < 0 && g.top) return g.top + (int64_t)(r + y) * g.s_row;
     if (y >= g.h && g.bot) return g.bot + (int64_t)(y - g.h) * g.s_row;
     return simg + (int64_t)reflect101(y, g.h) * g.s_row;
-}
-
-template <int C, int R>
-struct Win {                            // bytes [b0 - 4*HD, b0 + 16 + 4*HD) of one row, as dwords
-    static constexpr int HD = (R * C + 3) / 4;
-    static constexpr int ND = 4 + 2 * HD;
-    uint32_t w[ND];
-};
-
-template <int C, int R>
-__device__ __forceinline__ void load_win(Win<C, R>& W, const uint8_t* rp, int b0)
-{
-    constexpr int HD = Win<C, R>::HD;
-#if IPX_CONV_NT_LOADS
-    const u32x4 c = ld16_nt(rp + b0);
-    __builtin_memcpy(&W.w[HD], &c, 16);
-#else
-    __builtin_memcpy(&W.w[HD], rp + b0, 16);
-#endif
-#if IPX_ABLATE & 1          // dev ablation: no halo loads (results are wrong; timing only)
-#pragma unroll
-    for (int i = 0; i < HD; ++i) { W.w[i] = W.w[HD + i]; W.w[HD + 4 + i] = W.w[HD + 3 - i]; }
-#else
-    __builtin_memcpy(&W.w[0], rp + b0 - 4 * HD, 4 * HD);
-    __builtin_memcpy(&W.w[HD + 4], rp + b0 + 16, 4 * HD);
-#endif
-}
-
-// Field pair (byte p, byte p+2) of the window, zero-extended to 2 x u16; p is relative to b0 and static.
-template <int C, int R>
-__device__ __forceinline__ us2 fld(const Win<C, R>& W, int p)
-{
-    const int q = p + 4 * Win<C, R>::HD;
-    const int d = q >> 2, j = q & 3;
-    const uint32_t lo = W.w[d];
-    uint32_t v;
-    if (j == 0) {
-        v = lo & 0x00ff00ffu;
-    } else {
-        const uint32_t hi = j >= 2 ? W.w[d + 1] : lo;          // byte p+2 lives in the next dword
-        v = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)j | ((uint32_t)(j + 2) << 16));
-    }
-    return __builtin_bit_cast(us2, v);
-}
-
-// The 8 field pairs of a lane's 16 output bytes: slot s = 2*k + parity covers bytes (4k+parity, 4k+parity+2).
-__device__ __forceinline__ constexpr int slot_p(int s) { return 4 * (s >> 1) + (s & 1); }
-
-__device__ __forceinline__ uint32_t pack_fields(us2 even, us2 odd)      // fields hold 0..255
-{
-    return __builtin_bit_cast(uint32_t, even) | (__builtin_bit_cast(uint32_t, odd) << 8);
-}
-
-// D = lo16(p) * c + acc   /   D = hi16(p) * c + acc      (c in an SGPR)
-__device__ __forceinline__ uint32_t mad_lo16(uint32_t p, uint32_t c, uint32_t acc)
-{
-    uint32_t d;
-    asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(d) : "v"(p), "s"(c), "v"(acc));
-    return d;
-}
-__device__ __forceinline__ uint32_t mad_hi16(uint32_t p, uint32_t c, uint32_t acc)
-{
-    uint32_t d;
-    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(p), "s"(c), "v"(acc));
-    return d;
-}
-
-// Output dword from four 32-bit accumulators whose result byte sits in bits 16..23:
-// eL -> byte 0, oL -> byte 1, eH -> byte 2, oH -> byte 3.
-__device__ __forceinline__ uint32_t pack_acc(uint32_t eL, uint32_t oL, uint32_t eH, uint32_t oH)
-{
-    return __builtin_amdgcn_perm(oL, eL, 0x0c0c0602u) | __builtin_amdgcn_perm(oH, eH, 0x06020c0cu);
 }
 
 __device__ __forceinline__ ss2 pk_max(ss2 a, ss2 b) { return __builtin_elementwise_max(a, b); }
@@ -610,7 +535,10 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     if (k == 5) { launch_sep_small_c<5>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<5>"); return IPX_OK; }
     if (k == 7) { launch_sep_small_c<7>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<7>"); return IPX_OK; }
 
-    // generic two-pass path through a Q8.8 scratch image of (h + 2r) rows per image
+    if (k >= 9 && k <= 31)                                          // row-pass + column-pass kernels, ipx_sepbig.hip
+        return ipx_sep_mid(st, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, kx_q8, ky_q8, k, top_halo, bottom_halo);
+
+    // generic two-pass path through a Q8.8 scratch image of (h + 2r) rows per image (k = 1 and k > 31)
     if (n > 65535 || h + k > 65535) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: n or h too large for the two-pass path", fn);
     const int r = k / 2;
     const size_t tmp_bytes = (size_t)n * (size_t)(h + 2 * r) * (size_t)g.L * sizeof(uint16_t);
