@@ -202,9 +202,9 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void conv3_kernel(const uin
     }
     unsigned img; int y0, y1, lane0;
     if (!wave_item(g, img, y0, y1, lane0)) return;
-    const int lane = (int)(threadIdx.x & 63u);
-    if (lane >= g.lanes_per_strip || lane0 + lane >= g.nlanes) return;
-    const int b0 = 16 + 16 * (lane0 + lane);
+    const int gl = lane0 + (int)(threadIdx.x & 63u);         // 16-byte lane of the row; lane 0 is border
+    if (gl == 0 || gl > g.nlanes) return;
+    const int b0 = 16 * gl;
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     typedef Win<C, 1> W1;
@@ -289,9 +289,9 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
     }
     unsigned img; int y0, y1, lane0;
     if (!wave_item(g, img, y0, y1, lane0)) return;
-    const int lane = (int)(threadIdx.x & 63u);
-    if (lane >= g.lanes_per_strip || lane0 + lane >= g.nlanes) return;
-    const int b0 = 16 + 16 * (lane0 + lane);
+    const int gl = lane0 + (int)(threadIdx.x & 63u);         // 16-byte lane of the row; lane 0 is border
+    if (gl == 0 || gl > g.nlanes) return;
+    const int b0 = 16 * gl;
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     typedef Win<C, R> WR;
@@ -415,8 +415,11 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
     const int hd4 = 4 * ((r * c + 3) / 4);
     // main-region lane i covers bytes [16 + 16 i, 32 + 16 i) and reads hd4 bytes on either side of them
     g.nlanes = g.L >= 32 + hd4 ? (g.L - 32 - hd4) / 16 + 1 : 0;
-    g.nstrips = (g.nlanes + 63) / 64;
-    g.lanes_per_strip = g.nstrips ? (g.nlanes + g.nstrips - 1) / g.nstrips : 0;
+    // Strips are 64 lanes = 1 KiB of the row starting at byte 0, so that every wave's loads and stores cover whole
+    // 128-byte lines (measured: strips shifted by 16 bytes stream 10 % slower, scripts/dev/walkbench2.hip); lane 0 of
+    // strip 0 (border bytes) idles.
+    g.lanes_per_strip = 64;
+    g.nstrips = g.nlanes ? (g.nlanes + 1 + 63) / 64 : 0;
     // rows per segment: short enough for >= ~4 waves of work per wave slot, long enough to amortise the
     // 2r halo rows every segment re-reads
     int seg = env_int("IPX_SEG_ROWS", 0);

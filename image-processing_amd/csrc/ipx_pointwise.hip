@@ -39,7 +39,9 @@ __device__ __forceinline__ void load_lut(uint32_t* s_lut, const LutArg& lutv, co
     __syncthreads();
 }
 
-// dst = lut[src]; blockIdx.y = image, blockIdx.x grid-strides over the image's units.
+// dst = lut[src]; blockIdx.y = image, blockIdx.x grid-strides over the image's units.  The first unit's loads are
+// issued BEFORE the table is fetched and staged, so that a device-resident table (equalizeHist) costs no extra
+// round trip in these short-lived blocks.
 template <bool BYVAL, bool NT>
 __global__ __launch_bounds__(kThreads) void lut_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                        PwGeom g, LutArg lutv, const uint8_t* __restrict__ lut_dev,
@@ -47,10 +49,10 @@ __global__ __launch_bounds__(kThreads) void lut_kernel(const uint8_t* __restrict
 {
     __shared__ uint32_t s_lut[64];
     const unsigned img = blockIdx.y;
-    load_lut(s_lut, lutv, BYVAL ? nullptr : lut_dev + (int64_t)img * lut_stride, BYVAL);
     const uint8_t* sl = reinterpret_cast<const uint8_t*>(s_lut);
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    bool have_lut = false;
 
     for (unsigned u = blockIdx.x; u < g.units_per_img; u += gridDim.x) {
         const unsigned row = u / g.units_per_row;
@@ -62,6 +64,10 @@ __global__ __launch_bounds__(kThreads) void lut_kernel(const uint8_t* __restrict
         for (int j = 0; j < kUnroll; ++j) {
             const int64_t c = col0 + (int64_t)j * kChunk;
             if (c + 16 <= g.len) v[j] = ld16x<NT>(sp + c);
+        }
+        if (!have_lut) {                                     // block-uniform
+            load_lut(s_lut, lutv, BYVAL ? nullptr : lut_dev + (int64_t)img * lut_stride, BYVAL);
+            have_lut = true;
         }
 #pragma unroll
         for (int j = 0; j < kUnroll; ++j) {
