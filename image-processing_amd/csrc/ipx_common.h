@@ -74,6 +74,30 @@ __device__ __forceinline__ void load_px16(PxVec<C>& p, const uint8_t* s)
     for (int i = 0; i < C; ++i) p.q[i] = ld16x<NT>(s + 16 * i);
 }
 
+// 1024 BGR pixels (3 KiB) of one wave, loaded as three CONTIGUOUS 1 KiB wave accesses (lane i takes bytes
+// 1024 t + 16 i) and then transposed through a wave-private 3 KiB LDS region so that lane L ends up with its own 16
+// pixels (bytes 48 L .. 48 L + 47).  Measured (scripts/dev/graybench.hip): with nt loads this streams at 6.3 TB/s,
+// against 5.7 TB/s (default policy) / 5.0 TB/s (nt) when every lane loads its 48 bytes directly (48-byte lane stride).
+// The b128 reads at a 48-byte lane stride are bank-conflict free.  No block barrier: the region belongs to one wave.
+__device__ __forceinline__ void load_group3_nt(u32x4 (&v)[3], const uint8_t* group, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < 3; ++t) v[t] = ld16_nt(group + 1024 * t + 16 * lane);
+}
+__device__ __forceinline__ void transpose_group3(PxVec<3>& p, const u32x4 (&v)[3], uint8_t* wave_lds, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < 3; ++t) *reinterpret_cast<u32x4*>(wave_lds + 1024 * t + 16 * lane) = v[t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int t = 0; t < 3; ++t) p.q[t] = *reinterpret_cast<const u32x4*>(wave_lds + 48 * lane + 16 * t);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                       // the region may be rewritten after this point
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int C>
 __device__ __forceinline__ uint32_t px_byte(const PxVec<C>& p, int byte_index)   // static after unrolling
 {

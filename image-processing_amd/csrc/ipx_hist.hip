@@ -9,6 +9,7 @@
 // hist_finish_kernel: one block per image sums the per-block partials and (optionally) builds the
 //   equalization table with an LDS scan, in float32 exactly as OpenCV does.
 #include "ipx_common.h"
+#include <stdlib.h>
 
 extern "C" int ipx_lut_dev_u8(void*, const uint8_t*, uint8_t*, int, int, int, int, int64_t, int64_t, int64_t, int64_t,
                               const uint8_t*, int64_t);
@@ -98,7 +99,10 @@ __global__ __launch_bounds__(kThreads) void gray_hist_kernel(const uint8_t* __re
                                                              GrayHistGeom g, uint32_t* __restrict__ partial)
 {
     __shared__ uint32_t s_hist[256 * kCopies];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tr[C == 3 ? (kThreads / 64) * 3072 : 16];   // transpose_group3
     const unsigned tid = threadIdx.x, copy = tid & 31u;
+    const int lane = (int)(tid & 63u), wave = (int)(tid >> 6);
+    uint8_t* wlds = s_tr + (C == 3 ? wave * 3072 : 0);
 #pragma unroll
     for (int i = 0; i < 256 * kCopies / kThreads; ++i) s_hist[i * kThreads + tid] = 0;
     __syncthreads();
@@ -109,18 +113,27 @@ __global__ __launch_bounds__(kThreads) void gray_hist_kernel(const uint8_t* __re
     const unsigned u_end = (unsigned)((uint64_t)g.units_per_img * (blockIdx.x + 1) / gridDim.x);
     for (unsigned u = u_begin; u < u_end; ++u) {
         const unsigned row = u / g.units_per_row;
-        const int64_t px0 = (int64_t)(u - row * g.units_per_row) * kGUnit + (int64_t)tid * 16;
+        const int64_t gx0 = (int64_t)(u - row * g.units_per_row) * kGUnit + (int64_t)wave * 1024;   // wave's pixel group
         const uint8_t* sp = simg + (int64_t)row * g.s_row;
         uint8_t* gp = gimg + (int64_t)row * g.g_row;
         PxVec<C> p[2];
+        u32x4 raw[2][3];
+        bool full[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int64_t x = px0 + (int64_t)j * kChunk;
-            if (x + 16 <= g.len) load_px16<C, NT>(p[j], sp + x * C);
+            const int64_t gx = gx0 + (int64_t)j * kChunk, x = gx + 16 * lane;
+            full[j] = C == 3 && gx + 1024 <= g.len;       // wave-uniform
+            if (full[j]) load_group3_nt(raw[j], sp + gx * 3, lane);
+            else if (x + 16 <= g.len) load_px16<C, NT>(p[j], sp + x * C);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int64_t x = px0 + (int64_t)j * kChunk;
+            const int64_t x = gx0 + (int64_t)j * kChunk + 16 * lane;
+            if (C == 3 && full[j]) {
+                PxVec<3> q;
+                transpose_group3(q, raw[j], wlds, lane);
+                __builtin_memcpy(&p[j], &q, sizeof(q));
+            }
             if (x + 16 <= g.len) {
                 u32x4 o;
 #pragma unroll
@@ -234,11 +247,12 @@ HistGeom make_geom(int h, int w, int64_t s_row, int64_t s_img)
 
 // blocks per image: enough blocks to fill the chip (LDS admits 4-5 blocks per CU), but at least
 // 64 KiB of pixels per block so that zeroing/folding the 32 KiB LDS histogram stays in the noise.
-unsigned blocks_per_image(int n, int h, int w)
+unsigned blocks_per_image(int n, int h, int w, unsigned slots = 1024)
 {
     const uint64_t bytes = (uint64_t)h * (uint64_t)w;
     uint64_t by_work = (bytes + 65535) / 65536;
-    uint64_t by_chip = (1024 + (uint64_t)n - 1) / (uint64_t)n;   // 256 CUs x 4 resident blocks: one even round
+    if (const char* e = getenv("IPX_HIST_SLOTS")) { if (atoi(e) > 0) slots = (unsigned)atoi(e); }   // dev knob
+    uint64_t by_chip = (slots + (uint64_t)n - 1) / (uint64_t)n;  // 256 CUs x resident blocks per CU: one even round
     uint64_t b = by_work < by_chip ? by_work : by_chip;
     return (unsigned)(b < 1 ? 1 : b);
 }
@@ -402,7 +416,10 @@ int ipx_bgr2gray_equalize_u8(void* stream, const uint8_t* src, uint8_t* gray, ui
     if (src_row_stride == (int64_t)w * src_channels && gray_row_stride == w) { g.rows = 1; g.len = (int64_t)w * h; }
     g.units_per_row = ipx_div_up((uint64_t)g.len, kGUnit);
     g.units_per_img = (unsigned)g.rows * g.units_per_row;
-    unsigned bpi = blocks_per_image(n, h, w);
+    // 56 KiB of LDS per block (histogram + transposition): 2 resident blocks per CU; never more blocks than the
+    // workspace layout (sized by the default) holds
+    unsigned bpi = blocks_per_image(n, h, w, 512);
+    if (bpi > blocks_per_image(n, h, w)) bpi = blocks_per_image(n, h, w);
     if (bpi > g.units_per_img) bpi = g.units_per_img;
     const bool nt = ipx_use_nt((uint64_t)n * h * w * src_channels);
     auto k = src_channels == 3 ? (nt ? gray_hist_kernel<3, true> : gray_hist_kernel<3, false>)

@@ -84,48 +84,70 @@ __global__ __launch_bounds__(kThreads) void lut_kernel(const uint8_t* __restrict
     }
 }
 
-// dst = gray(src) or lut[gray(src)]; lane = 16 pixels (48 or 64 source bytes -> 16 output bytes)
+// 16 gray (or table[gray]) bytes from a lane's 16 pixels
+template <int C, bool WITH_LUT>
+__device__ __forceinline__ u32x4 gray16(const PxVec<C>& p, const uint8_t* sl)
+{
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = 4 * k + i;
+            uint32_t y = gray_q15(px_byte<C>(p, px * C), px_byte<C>(p, px * C + 1), px_byte<C>(p, px * C + 2));
+            if (WITH_LUT) y = sl[y];
+            word |= y << (8 * i);
+        }
+        o[k] = word;
+    }
+    return o;
+}
+
+// dst = gray(src) or lut[gray(src)]; lane = 16 pixels (48 or 64 source bytes -> 16 output bytes).
+// BGR: a wave whose 1024 pixels all lie inside the row takes them as three contiguous 1 KiB nt loads and sorts them
+// out through LDS (transpose_group3); ragged groups and BGRA use per-lane loads.
 template <int C, bool WITH_LUT, bool NT>
 __global__ __launch_bounds__(kThreads) void gray_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                         PwGeom g, LutArg lutv)
 {
     __shared__ uint32_t s_lut[64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tr[C == 3 ? (kThreads / 64) * 3072 : 16];
     if (WITH_LUT) load_lut(s_lut, lutv, nullptr, true);
     const uint8_t* sl = reinterpret_cast<const uint8_t*>(s_lut);
     const unsigned img = blockIdx.y;
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     constexpr int U = 2;                                  // 2 x (3|4) x 16 B loads in flight per lane
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wave = (int)(threadIdx.x >> 6);
+    uint8_t* wlds = s_tr + (C == 3 ? wave * 3072 : 0);
 
     for (unsigned u = blockIdx.x; u < g.units_per_img; u += gridDim.x) {
         const unsigned row = u / g.units_per_row;
-        const int64_t px0 = (int64_t)(u - row * g.units_per_row) * (kChunk * U) + (int64_t)threadIdx.x * 16;
+        const int64_t gx0 = (int64_t)(u - row * g.units_per_row) * (kChunk * U) + (int64_t)wave * 1024;   // wave's group
         const uint8_t* sp = simg + (int64_t)row * g.s_row;
         uint8_t* dp = dimg + (int64_t)row * g.d_row;
         PxVec<C> p[U];
+        u32x4 raw[U][3];
+        bool full[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int64_t x = px0 + (int64_t)j * kChunk;
-            if (x + 16 <= g.len) load_px16<C, NT>(p[j], sp + x * C);
+            const int64_t gx = gx0 + (int64_t)j * kChunk, x = gx + 16 * lane;
+            full[j] = C == 3 && gx + 1024 <= g.len;       // wave-uniform
+            if (full[j]) load_group3_nt(raw[j], sp + gx * 3, lane);
+            else if (x + 16 <= g.len) load_px16<C, NT>(p[j], sp + x * C);
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
-            const int64_t x = px0 + (int64_t)j * kChunk;
+            const int64_t x = gx0 + (int64_t)j * kChunk + 16 * lane;
+            if (C == 3 && full[j]) {
+                PxVec<3> q;
+                transpose_group3(q, raw[j], wlds, lane);
+                __builtin_memcpy(&p[j], &q, sizeof(q));
+            }
             if (x + 16 <= g.len) {
-                u32x4 o;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t word = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int px = 4 * k + i;
-                        uint32_t y = gray_q15(px_byte<C>(p[j], px * C), px_byte<C>(p[j], px * C + 1), px_byte<C>(p[j], px * C + 2));
-                        if (WITH_LUT) y = sl[y];
-                        word |= y << (8 * i);
-                    }
-                    o[k] = word;
-                }
-                st16x<NT>(dp + x, o);
+                st16x<NT>(dp + x, gray16<C, WITH_LUT>(p[j], sl));
             } else if (x < g.len) {
                 for (int64_t q = x; q < g.len; ++q) {
                     const uint8_t* s = sp + q * C;
