@@ -44,6 +44,7 @@ SIGNATURES = {
     "ipx_gauss_kernel_q8": (_i, [_i, C.c_double, _vp]),
     "ipx_sep_filter_q8_u8": (_i, _IMG + [_i] + _STR + [_vp, _vp, _i, _vp, _vp]),
     "ipx_gaussian_blur_u8": (_i, _IMG + [_i] + _STR + [_i, _vp, _vp]),
+    "ipx_lee_filter_u8": (_i, _IMG + _STR + [_i]),
 }
 
 _lib = None

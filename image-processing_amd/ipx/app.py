@@ -20,7 +20,8 @@ from flask import Flask, jsonify, request
 
 from . import codec, luts
 
-OUT_OF_SCOPE = ("pca_nn", "count_objects", "denoise_manual", "frequency_filter", "wiener", "median")
+OUT_OF_SCOPE = ("pca_nn", "count_objects", "frequency_filter", "wiener", "median")
+DENOISE_OUT_OF_SCOPE = ("median", "bilateral", "nlm")    # cv2 rank / edge-preserving / patch filters
 
 
 class GpuBackend:
@@ -42,6 +43,9 @@ class GpuBackend:
         if s is None:
             s = self._tls.stream = self.torch.cuda.Stream(device=self.device)
         return s
+
+    def stats_from_hist(self, hist, method_name):
+        return self.ops.stats_from_hist(hist, method_name)
 
     def run(self, fn, *arrays):
         """Stage arrays to the device, run fn(ops, *tensors) on this thread's stream, bring results back."""
@@ -89,6 +93,26 @@ def create_app(backend=None) -> Flask:
             if mode in OUT_OF_SCOPE:
                 return jsonify({"error": f"mode '{mode}' is outside the GPU hot path of this backend "
                                          "(convolution filters, histogram equalization, pixel-wise transforms)"}), 501
+
+            if mode == "denoise_manual":                                # server.py:181-241; method=lee runs on the GPU
+                img = ensure_gray_uint8(b, data)
+                method_name = request.form.get("method", "median")
+                kernel = int(request.form.get("kernel", "5"))
+                if kernel % 2 == 0:
+                    kernel += 1
+                kernel = max(3, min(31, kernel))
+                if method_name != "lee":                                 # every other branch is a cv2 filter (C10)
+                    return jsonify({"error": f"denoise_manual method '{method_name}' is outside the GPU hot path of this "
+                                             "backend (only method=lee is built: SURVEY.md section 8(f))"}), 501
+                # histogram analysis (server.py:190-211) from the GPU's exact 256-bin histogram, Lee filter on the GPU
+                hist, img_denoised = b.run(lambda ops, t: (ops.hist(t), ops.lee_filter(t, kernel)), img)
+                st = b.stats_from_hist(hist, method_name)
+                method = f"Lee Filter (w={kernel})"
+                params = {"method": method, "kernel": kernel,
+                          "histogram": {"extreme_ratio": round(st["extreme_ratio"], 4), "variance": round(st["variance"], 2),
+                                        "cv": round(st["cv"], 4), "suggested_method": st["suggested_method"]}}
+                return jsonify({"dataURL": codec.to_data_url_png(img_denoised), "message": f"Manual denoise: {method}",
+                                "params": params}), 200
 
             if mode == "histogram_eq":                                  # server.py:243-248
                 img = codec.decode_unchanged(data)

@@ -278,3 +278,47 @@ def gaussian_blur(src, k: int, top_halo=None, bottom_halo=None) -> torch.Tensor:
         _lib.call("ipx_gaussian_blur_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w, s.c,
                   s.row, s.img, s.w * s.c, s.w * s.c * s.h, int(k), tp, bp)
     return s.restore(out)
+
+
+# ---- Lee filter, denoise_manual statistics -------------------------------
+def lee_filter(src: torch.Tensor, window_size: int = 5) -> torch.Tensor:
+    """lee_filter(img, window_size) (server.py:711-732): float32 window mean/variance blend on interior pixels."""
+    s = _gray(src)
+    with torch.cuda.device(s.t.device):
+        out = s.like()
+        _lib.call("ipx_lee_filter_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w,
+                  s.row, s.img, s.w, s.w * s.h, int(window_size))
+    return s.restore(out)
+
+
+def denoise_stats(src: torch.Tensor, method_name: str = "median") -> dict:
+    """The histogram analysis of mode=denoise_manual (server.py:190-211) for ONE gray image, from the exact 256-bin
+    histogram of the GPU: extreme_ratio = (count(0) + count(255)) / total, mean, variance, cv = std / mean and the
+    suggested method.  The reference reduces the float32 pixel array with numpy (pairwise float32 sums, relative error
+    ~1e-6 on megapixel images); here the moments come from integer counts in float64, so the values agree with the
+    reference's to float32 rounding, not bit for bit (tolerance stated in tests/test_gpu_parity.py)."""
+    if src.ndim != 2:
+        raise ValueError("denoise_stats: one H x W gray image expected")
+    h = hist(src).to("cpu").numpy().astype(np.int64)
+    return stats_from_hist(h, method_name)
+
+
+def stats_from_hist(h: np.ndarray, method_name: str = "median") -> dict:
+    """server.py:190-211 from a 256-bin histogram (host arithmetic, float64)."""
+    h = np.asarray(h, np.int64)
+    total = float(h.sum())
+    extreme_ratio = float((int(h[0]) + int(h[255])) / total)
+    lv = np.arange(256, dtype=np.float64)
+    mean_val = float((h * lv).sum() / total)
+    var = float((h * (lv - mean_val) ** 2).sum() / total)
+    cv_val = float(np.sqrt(var) / (mean_val + 1e-12))
+    if extreme_ratio > 0.02:
+        suggested = "median"
+    elif cv_val > 0.28:
+        suggested = "lee"
+    elif 100 < var < 2000:
+        suggested = "bilateral"
+    else:
+        suggested = method_name
+    return {"extreme_ratio": extreme_ratio, "mean": mean_val, "variance": var, "cv": cv_val,
+            "suggested_method": suggested}

@@ -166,6 +166,18 @@ int ipx_gaussian_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
                          int64_t dst_row_stride, int64_t dst_img_stride, int k,
                          const uint8_t* top_halo, const uint8_t* bottom_halo);
 
+/* ---- speckle filter ---------------------------------------- */
+
+/* lee_filter(img, window_size) -- server.py:711-732, reached through mode=denoise_manual with
+ * method=lee (server.py:224-226).  Gray images only, as in the reference.  k = window_size / 2; for
+ * every interior pixel (k <= y < h-k, k <= x < w-k) the float32 mean and variance of its
+ * (2k+1) x (2k+1) window are formed exactly as numpy forms them (pairwise float32 summation) and
+ * out = mean + var / (var + mean^2 / (mean + 1e-12)) * (pixel - mean), or mean where var == 0;
+ * clip to [0,255] and truncate.  Border pixels keep their input value.  window_size in 1..31. */
+int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                      int64_t src_row_stride, int64_t src_img_stride,
+                      int64_t dst_row_stride, int64_t dst_img_stride, int window_size);
+
 #ifdef __cplusplus
 }
 #endif

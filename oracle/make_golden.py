@@ -161,6 +161,20 @@ def main():
     for wnd in (3, 5, 7):
         arrays[f"out_lee_{wnd}"] = server.lee_filter(speck, window_size=wnd)
 
+    for wnd in (9, 15, 31):                     # large windows: numpy's pairwise sum recurses above 128 values
+        arrays[f"out_lee_rand_{wnd}"] = server.lee_filter(imgs["rand"], window_size=wnd)
+
+    # mode=denoise_manual with method=lee through the real dispatch (server.py:181-241): histogram statistics
+    # (extreme_ratio, variance, cv, suggested_method) and the Lee output, all numpy inside the reference
+    sp = imgs["rand"].copy()
+    m = np.random.default_rng(11).random(sp.shape)
+    sp = np.where(m < 0.03, 0, np.where(m > 0.97, 255, (sp // 4 + 90))).astype(np.uint8)   # salt & pepper
+    imgs["saltpepper"] = sp
+    imgs["lee"] = speck
+    arrays["in_saltpepper"] = sp
+    for key, kern in (("rand", 5), ("lee", 4), ("narrow", 7), ("const", 3), ("saltpepper", 5), ("lowmax", 40), ("ramp", 9)):
+        case(f"denoise_lee_{key}_{kern}", key, "denoise_manual", method="lee", kernel=kern)
+
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, "server_numpy_ops.npz"), **arrays)
     meta = {

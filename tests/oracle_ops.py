@@ -60,8 +60,16 @@ class OracleOps:
         return _with_halo(t, top_halo, bottom_halo, k // 2, lambda a: O.gaussian_blur_u8(a, k))
 
 
+    @staticmethod
+    def lee_filter(t, window_size=5): return _t(O.lee_filter_u8(_np(t), window_size))
+
+
 class OracleBackend:
     """app.GpuBackend stand-in: numpy in, numpy out."""
+    def stats_from_hist(self, hist, method_name):
+        import ipx.ops as real_ops                      # pure host arithmetic on 256 counts (no GPU involved)
+        return real_ops.stats_from_hist(hist, method_name)
+
     def run(self, fn, *arrays):
         out = fn(OracleOps, *[_t(a) for a in arrays])
         if isinstance(out, tuple):

@@ -229,6 +229,11 @@ def test_golden_server_cases_on_device(dev, golden):
         img, out = g["in_" + c["input"]], g["out_" + c["name"]]
         t = dev_t(img, dev)
         mode = c["mode"] or "gray8"
+        if mode == "denoise_manual":                          # real lee_filter output through the real dispatch
+            from test_oracle_golden import _lee_kernel
+            np.testing.assert_array_equal(host(ops.lee_filter(t, _lee_kernel(c["form"]))), out, err_msg=c["name"])
+            n += 1
+            continue
         if mode in ("log", "logarithmic", "logrithmic"):
             present = host(ops.hist(t))                       # device histogram feeds s.max()
             lut = luts.log(float(c["form"].get("c", "2.0")), present)
@@ -237,6 +242,49 @@ def test_golden_server_cases_on_device(dev, golden):
         np.testing.assert_array_equal(host(ops.apply_lut(t, lut)), out, err_msg=c["name"])
         n += 1
     assert n >= 60
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (5, 40), (28, 36), (33, 70), (64, 97), (130, 96)])
+@pytest.mark.parametrize("wnd", [1, 3, 4, 5, 7, 9, 15, 31])
+def test_lee_filter(dev, shape, wnd):
+    """server.py:711-732 bit for bit (float32 mean / pairwise-summed variance per window), incl. images smaller than
+    the window (all border) and flat patches (var == 0)."""
+    rng = np.random.default_rng(shape[0] * 131 + wnd)
+    img = np.clip(rng.normal(120, 40, shape), 0, 255).astype(np.uint8)
+    if shape[0] > 12 and shape[1] > 20:
+        img[3:12, 4:20] = 61
+    np.testing.assert_array_equal(host(ops.lee_filter(dev_t(img, dev), wnd)), O.lee_filter_u8(img, wnd))
+
+
+def test_lee_filter_golden_and_batch(dev, golden):
+    g, _ = golden
+    for w in (3, 5, 7):
+        np.testing.assert_array_equal(host(ops.lee_filter(dev_t(g["in_lee"], dev), w)), g[f"out_lee_{w}"])
+    for w in (9, 15, 31):
+        np.testing.assert_array_equal(host(ops.lee_filter(dev_t(g["in_rand"], dev), w)), g[f"out_lee_rand_{w}"])
+    rng = np.random.default_rng(3)
+    batch = rng.integers(0, 256, (3, 50, 77, 1), dtype=np.uint8)
+    got = host(ops.lee_filter(dev_t(batch, dev), 5))
+    for i in range(3):
+        np.testing.assert_array_equal(got[i, :, :, 0], O.lee_filter_u8(batch[i, :, :, 0], 5))
+    extremes = np.where(rng.random((40, 60)) < 0.5, 0, 255).astype(np.uint8)
+    np.testing.assert_array_equal(host(ops.lee_filter(dev_t(extremes, dev), 7)), O.lee_filter_u8(extremes, 7))
+
+
+def test_denoise_stats_on_device(dev):
+    """server.py:190-211 from the device histogram: flags equal, moments equal to float32 rounding (the reference
+    reduces float32 pixels with numpy; the product uses exact counts in float64)."""
+    rng = np.random.default_rng(9)
+    for img in (rng.integers(0, 256, (300, 411), dtype=np.uint8),
+                np.clip(rng.normal(128, 12, (256, 256)), 0, 255).astype(np.uint8),
+                np.where(rng.random((200, 200)) < 0.05, 255, 100).astype(np.uint8)):
+        ref = O.denoise_stats(img, "nlm")
+        got = ops.denoise_stats(dev_t(img, dev), "nlm")
+        assert got["suggested_method"] == ref["suggested_method"]
+        assert got["extreme_ratio"] == ref["extreme_ratio"]
+        assert abs(got["mean"] - ref["mean"]) <= 2e-6 * ref["mean"]
+        assert abs(got["variance"] - ref["variance"]) <= 4e-6 * max(1.0, ref["variance"])
+        assert abs(got["cv"] - ref["cv"]) <= 4e-6
 
 
 def test_full_size_properties(dev):

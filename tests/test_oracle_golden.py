@@ -17,7 +17,15 @@ def _expected(O, img, mode, form):
         return O.log_u8(img, float(form.get("c", "2.0")))
     if mode in ("piecewise", "piecewise_linear", "stretch"):
         return O.piecewise_u8(img, *[int(form[k]) for k in ("r1", "s1", "r2", "s2")])
+    if mode == "denoise_manual":
+        return O.lee_filter_u8(img, _lee_kernel(form))
     return img          # gray8 / default / unknown mode on a gray input
+
+
+def _lee_kernel(form):
+    k = int(form.get("kernel", "5"))                       # server.py:185-188
+    k += 1 if k % 2 == 0 else 0
+    return max(3, min(31, k))
 
 
 def _lut_for(mode, form, img):
@@ -48,7 +56,7 @@ def test_host_luts_match_real_server_outputs(golden):
     """LUT built on 256 levels, then applied == the reference's whole-image evaluation (bit-exact)."""
     g, meta = golden
     for c in meta["cases"]:
-        if c["status"] != 200:
+        if c["status"] != 200 or c["mode"] == "denoise_manual":
             continue
         img, out = g["in_" + c["input"]], g["out_" + c["name"]]
         lut = _lut_for(c["mode"] or "gray8", c["form"], img)
@@ -59,6 +67,29 @@ def test_lee_filter_matches_real_server(golden):
     g, _ = golden
     for w in (3, 5, 7):
         np.testing.assert_array_equal(O.lee_filter_u8(g["in_lee"], w), g[f"out_lee_{w}"])
+    for w in (9, 15, 31):
+        np.testing.assert_array_equal(O.lee_filter_u8(g["in_rand"], w), g[f"out_lee_rand_{w}"])
+
+
+def test_denoise_stats_match_real_server(golden):
+    """server.py:190-211 as the real server reported them (rounded in its JSON): the oracle (numpy float32, as the
+    reference) reproduces them exactly; the product's histogram form (float64 on exact counts) to float32 rounding."""
+    import ipx.ops as real_ops                              # stats_from_hist is host arithmetic on 256 counts
+    g, meta = golden
+    n = 0
+    for c in meta["cases"]:
+        if c["mode"] != "denoise_manual":
+            continue
+        img, ref = g["in_" + c["input"]], c["params"]["histogram"]
+        s = O.denoise_stats(img, "lee")
+        assert (round(s["extreme_ratio"], 4), round(s["variance"], 2), round(s["cv"], 4), s["suggested_method"]) == \
+               (ref["extreme_ratio"], ref["variance"], ref["cv"], ref["suggested_method"]), c["name"]
+        p = real_ops.stats_from_hist(np.bincount(img.ravel(), minlength=256), "lee")
+        assert p["suggested_method"] == ref["suggested_method"]
+        assert abs(p["variance"] - s["variance"]) <= 2e-6 * max(1.0, s["variance"])
+        assert abs(p["cv"] - s["cv"]) <= 2e-6 and abs(p["extreme_ratio"] - s["extreme_ratio"]) <= 1e-12
+        n += 1
+    assert n >= 7
 
 
 def test_piecewise_probe_from_survey():
