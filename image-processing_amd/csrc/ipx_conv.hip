@@ -11,16 +11,17 @@
 // ragged tail behind the last full lane are computed by "border" blocks appended to the same launch with plain
 // per-byte code (REFLECT_101 in pixel space).  Tiny images are all border.
 // Neighbouring strips are consecutive work items and the block->item map is XCD-aware so that they share an L2.
-// 9..31 taps: ipx_sepbig.hip (row-pass kernel + column-pass kernel around a Q8.8 scratch image).  Anything larger
+// 9..31 taps: ipx_sepmfma.hip (both passes as banded int8 matrix products on the MFMA units; taps above 127 fall back
+// to ipx_sepbig.hip, a row-pass kernel + column-pass kernel around a Q8.8 scratch image).  Anything larger
 // (and k = 1) goes through the simple generic two-pass path at the bottom of this file.
 #include "ipx_common.h"
 #include "ipx_fields.h"
 #include <stdlib.h>
 #include <vector>
 
-int ipx_sep_mid(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
-                int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
-                const uint16_t* kx, const uint16_t* ky, int k, const uint8_t* top, const uint8_t* bot);
+int ipx_sep_mfma(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+                 int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
+                 const uint16_t* kx, const uint16_t* ky, int k, const uint8_t* top, const uint8_t* bot);
 
 namespace {
 
@@ -538,8 +539,8 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     if (k == 5) { launch_sep_small_c<5>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<5>"); return IPX_OK; }
     if (k == 7) { launch_sep_small_c<7>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<7>"); return IPX_OK; }
 
-    if (k >= 9 && k <= 31)                                          // row-pass + column-pass kernels, ipx_sepbig.hip
-        return ipx_sep_mid(st, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, kx_q8, ky_q8, k, top_halo, bottom_halo);
+    if (k >= 9 && k <= 31)                                          // int8 MFMA kernel, ipx_sepmfma.hip (VALU fallback: ipx_sepbig.hip)
+        return ipx_sep_mfma(st, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, kx_q8, ky_q8, k, top_halo, bottom_halo);
 
     // generic two-pass path through a Q8.8 scratch image of (h + 2r) rows per image (k = 1 and k > 31)
     if (n > 65535 || h + k > 65535) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: n or h too large for the two-pass path", fn);

@@ -170,9 +170,40 @@ def test_gaussian_c2_and_asymmetric_taps(dev):
     np.testing.assert_array_equal(host(ops.sep_filter_q8(dev_t(img, dev), k9, k9[::-1])), O.sep_filter_q8_u8(img, k9, k9[::-1]))
 
 
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_large_kernels_matrix_core_path(dev, cn):
+    """9..31 taps run as banded int8 matrix products (ipx_sepmfma.hip): asymmetric taps (kx != ky, neither palindromic),
+    every channel count, shapes around the 64 x 128 tile, batches with padded strides, extreme values."""
+    rng = np.random.default_rng(40 + cn)
+    def taps(k):
+        t = rng.integers(0, 9, k)
+        t[rng.integers(0, k)] += 256 - t.sum()              # sums to 256, every tap <= 127 for k >= 9? enforce below
+        while t.max() > 127:
+            i, j = int(t.argmax()), int(t.argmin())
+            t[i] -= 20; t[j] += 20
+        assert t.sum() == 256 and t.min() >= 0
+        return [int(v) for v in t]
+    for shape, k in (((70, 50), 9), ((64, 128), 13), ((65, 129), 17), ((131, 300), 31), ((9, 700), 21), ((200, 33), 27)):
+        img = rng.integers(0, 256, shape + ((cn,) if cn > 1 else ()), dtype=np.uint8)
+        kx, ky = taps(k), taps(k)
+        np.testing.assert_array_equal(host(ops.sep_filter_q8(dev_t(img, dev), kx, ky)), O.sep_filter_q8_u8(img, kx, ky),
+                                      err_msg=f"{shape} k={k}")
+    ext = np.where(rng.random((90, 260, cn)) < 0.5, 0, 255).astype(np.uint8)
+    ext = ext[:, :, 0] if cn == 1 else ext
+    for k in (11, 31):
+        np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(ext, dev), k)), O.gaussian_blur_u8(ext, k))
+    big = rng.integers(0, 256, (3, 80, 300 * cn + 5), dtype=np.uint8)
+    view = dev_t(big, dev)[:, 3:75, 2:2 + 290 * cn].unflatten(2, (290, cn))      # strided batch, unaligned base
+    ref_in = big[:, 3:75, 2:2 + 290 * cn].reshape(3, 72, 290, cn)
+    got = host(ops.gaussian_blur(view, 15))
+    for i in range(3):
+        want = O.gaussian_blur_u8(ref_in[i] if cn > 1 else ref_in[i][:, :, 0], 15)
+        np.testing.assert_array_equal(got[i] if cn > 1 else got[i][:, :, 0], want)
+
+
 def test_gaussian_max_values_do_not_overflow(dev):
     img = np.full((40, 1200, 3), 255, np.uint8)
-    for k in (3, 5, 7, 15):
+    for k in (3, 5, 7, 15, 31):
         np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(img, dev), k)), img)
 
 
@@ -206,7 +237,7 @@ def test_halo_rows_equal_whole_image(dev, cn):
     t = dev_t(img, dev)
     for name, ref, r in [("laplacian_sharpen", O.laplacian_sharpen_u8, 1), ("box3", O.box3_u8, 1),
                          ("sobel", O.sobel_u8, 1), ("g5", lambda a: O.gaussian_blur_u8(a, 5), 2),
-                         ("g9", lambda a: O.gaussian_blur_u8(a, 9), 4)]:
+                         ("g9", lambda a: O.gaussian_blur_u8(a, 9), 4), ("g31", lambda a: O.gaussian_blur_u8(a, 31), 15)]:
         whole = ref(img)
         for (y0, y1) in ((0, 30), (30, 61), (61, 90)):
             top = t[y0 - r:y0] if y0 > 0 else None
