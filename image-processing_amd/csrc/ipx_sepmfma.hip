@@ -18,6 +18,8 @@
 // taps; other kernels fall back to ipx_sepbig.hip.  The A/B fragments only rely on A and B sharing the k order inside
 // an instruction (sums are order-free in integers).
 #include "ipx_common.h"
+#include <stdlib.h>
+#include <stdio.h>
 
 int ipx_sep_mid(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
                 int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
@@ -36,9 +38,13 @@ struct MGeom {
     int h, w, L, r, K;
     int64_t s_row, s_img, d_row, d_img;
     int tiles_x, tiles_y;
-    unsigned ntiles;
+    int pw, ph, patches_x, patches_y;                // an XCD's blocks work on a pw x ph patch of tiles at a time
+    unsigned npatches;
     const uint8_t* top;
     const uint8_t* bot;
+    int ablate;                                      // dev: skip phases (timing only, results wrong)
+    int fast32;                                      // row strides small enough for 32-bit in-tile byte offsets
+    long long* prof;                                 // dev: phase time stamps of block 0 (IPX_MFMA_PROF), else null
 };
 struct MTaps { uint8_t kx[32]; uint8_t ky[32]; };
 
@@ -49,60 +55,106 @@ __device__ __forceinline__ const uint8_t* src_row(const MGeom& g, const uint8_t*
     return simg + (int64_t)reflect101(y, g.h) * g.s_row;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding GLOBAL loads
+// (vmcnt(0)), which would serialise the next tile's prefetch behind every barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ v4i lds16(const uint8_t* p) { return *reinterpret_cast<const v4i*>(p); }
 
 template <int C, int HL>
-__global__ __launch_bounds__(kThreads) void sep_mfma_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                            MGeom g, MTaps taps)
+__global__ __launch_bounds__(kThreads, 2) void sep_mfma_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                               MGeom g, MTaps taps)
 {
     constexpr int KSH = (16 + 2 * HL + 63) / 64;                 // k-steps of the row pass
     constexpr int SW = TX + 2 * HL;                              // source tile width in bytes
     constexpr int PS = HL <= 48 ? 240 : 272;                     // source pitch: >= SW, = 16 or 240 mod 256
     constexpr int NCH = SW / 16;
+    constexpr int NLD = kRowsS / 16;                             // source rows per thread: rows (tid >> 4) + 16 i
     __shared__ __attribute__((aligned(16))) uint8_t s_src[kRowsS * PS + 64 * KSH];   // also the result staging tile
     __shared__ __attribute__((aligned(16))) uint8_t s_ht[2][TX * kPitchH];
     __shared__ uint8_t s_taps[64];
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, gq = lane >> 4;
-    const unsigned tile = xcd_remap(blockIdx.x, g.ntiles);
-    const int tx = (int)(tile % (unsigned)g.tiles_x);
-    const int ty = (int)(tile / (unsigned)g.tiles_x % (unsigned)g.tiles_y);
-    const unsigned img = tile / ((unsigned)g.tiles_x * (unsigned)g.tiles_y);
-    const int x0 = tx * TX, y0 = ty * TY;
-    const uint8_t* simg = src + (int64_t)img * g.s_img;
     const int r = g.r, K = g.K, RY = TY + 2 * r;
+    const int lrow = tid >> 4, lch = tid & 15;                   // chunk column lch < NCH (NCH <= 16)
 
     if (tid < 64) s_taps[tid] = tid < 32 ? taps.kx[tid] : taps.ky[tid - 32];
 
-    // ---- 1. source tile -> LDS (signed bytes) ----------------------------------------------------------------
-    for (int idx = tid; idx < RY * NCH; idx += kThreads) {
-        const int row = idx / NCH, ch = idx - row * NCH;
-        int ys = y0 - r + row;
-        if (ys > g.h + r - 1) ys = g.h + r - 1;                     // rows below the last one anybody needs: clamp
-        const uint8_t* rp = src_row(g, simg, ys);
-        const int gx = x0 - HL + 16 * ch;
-        u32x4 v;
-        if (gx >= 0 && gx + 16 <= g.L) {
-            v = ld16(rp + gx);
-        } else {                                                  // image border: REFLECT_101 in pixel space
-            uint32_t wds[4] = {0, 0, 0, 0};
+    // Blocks b, b + 8, b + 16, ... share an XCD (round-robin dispatch), so block b = 8 q + x is tile q of the pw x ph
+    // patch that XCD x works on; the XCD walks patches x, x + 8, x + 16, ...  Neighbouring tiles of a patch are in
+    // flight together and share their halos through that XCD's L2.  The next TWO tiles of a block are prefetched into
+    // registers while the current one is filtered.  Patch coordinates advance incrementally (no divisions per tile).
+    struct Pos { int ppx, ppy; unsigned img, P; };
+    const int q = (int)(blockIdx.x >> 3), qx = q % g.pw, qy = q / g.pw;
+    const int ddx = 8 % g.patches_x, ddy = 8 / g.patches_x % g.patches_y;
+    const unsigned ddi = 8u / ((unsigned)g.patches_x * (unsigned)g.patches_y);
+    auto advance = [&](Pos p) {
+        p.P += 8;
+        p.ppx += ddx; if (p.ppx >= g.patches_x) { p.ppx -= g.patches_x; ++p.ppy; }
+        p.ppy += ddy; if (p.ppy >= g.patches_y) { p.ppy -= g.patches_y; ++p.img; }
+        p.img += ddi;
+        return p;
+    };
+    auto tile_x = [&](const Pos& p) { return p.ppx * g.pw + qx; };
+    auto tile_y = [&](const Pos& p) { return p.ppy * g.ph + qy; };
+    auto valid = [&](const Pos& p) { return p.P < g.npatches && tile_x(p) < g.tiles_x && tile_y(p) < g.tiles_y; };
+    // per-lane byte offsets of its NLD source chunks inside an interior tile (idle lanes re-load a clamped address,
+    // so that no load sits behind a branch and all NLD stay in flight)
+    unsigned loff[NLD];
 #pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const int col = gx + b;
-                int px = col >= 0 ? col / C : -((-col + C - 1) / C);
-                const int chn = col - px * C;
-                if (px >= -r && px <= g.w - 1 + r) {              // columns further out are never used
-                    px = reflect101(px, g.w);
-                    wds[b >> 2] |= (uint32_t)rp[px * C + chn] << (8 * (b & 3));
-                }
-            }
-            v = (u32x4){wds[0], wds[1], wds[2], wds[3]};
+    for (int i = 0; i < NLD; ++i)
+        loff[i] = (unsigned)((lrow + 16 * i < RY ? lrow + 16 * i : RY - 1) * (int)g.s_row + 16 * (lch < NCH ? lch : NCH - 1));
+
+    auto fetch = [&](const Pos& p, u32x4 (&reg)[NLD]) {
+        const uint8_t* simg = src + (int64_t)p.img * g.s_img;
+        const int xs0 = tile_x(p) * TX - HL, ys0 = tile_y(p) * TY - r;
+        if (g.fast32 && xs0 >= 0 && xs0 + SW <= g.L && ys0 >= 0 && ys0 + RY <= g.h) {   // interior tile (block-uniform)
+            const uint8_t* base = simg + (int64_t)ys0 * g.s_row + xs0;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) reg[i] = ld16(base + loff[i]);
+            return;
         }
-        v ^= (u32x4)(0x80808080u);
-        *reinterpret_cast<u32x4*>(s_src + row * PS + 16 * ch) = v;
-    }
-    __syncthreads();
+        // border tiles (a few per cent of all): still branch-free per row so that the loads overlap.  Rows come from
+        // src_row (REFLECT_101 or the caller's halo rows); a tile that crosses the left/right image edge gathers its
+        // bytes one by one with REFLECT_101 in pixel space (16 independent byte loads per chunk).
+        const int gx = xs0 + 16 * (lch < NCH ? lch : NCH - 1);
+        const bool xin = xs0 >= 0 && xs0 + SW <= g.L;            // block-uniform
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int row = lrow + 16 * i < RY ? lrow + 16 * i : RY - 1;
+            int ys = ys0 + row;
+            if (ys > g.h + r - 1) ys = g.h + r - 1;                 // rows below the last one anybody needs: clamp
+            const uint8_t* rp = src_row(g, simg, ys);
+            if (xin) {
+                reg[i] = ld16(rp + gx);
+            } else {
+                int off[16];
+#pragma unroll
+                for (int b = 0; b < 16; ++b) {
+                    const int col = gx + b;
+                    int px = col >= 0 ? col / C : -((-col + C - 1) / C);
+                    const int chn = col - px * C;
+                    px = px < -r ? -r : px > g.w - 1 + r ? g.w - 1 + r : px;   // further out: never used, keep it cheap
+                    off[b] = reflect101(px, g.w) * C + chn;
+                }
+                uint32_t wds[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int b = 0; b < 16; ++b) wds[b >> 2] |= (uint32_t)rp[off[b]] << (8 * (b & 3));
+                reg[i] = (u32x4){wds[0], wds[1], wds[2], wds[3]};
+            }
+        }
+    };
+    Pos pa;
+    pa.P = blockIdx.x & 7u;
+    pa.ppx = (int)(pa.P % (unsigned)g.patches_x);
+    pa.ppy = (int)(pa.P / (unsigned)g.patches_x % (unsigned)g.patches_y);
+    pa.img = pa.P / ((unsigned)g.patches_x * (unsigned)g.patches_y);
+    Pos pb = advance(pa);
+    u32x4 bufa[NLD], bufb[NLD];
+    if (valid(pa)) fetch(pa, bufa);
+    if (valid(pb)) fetch(pb, bufb);
+    __syncthreads();                                              // s_taps
 
     // ---- Toeplitz operands (registers, the same for every tile) ----------------------------------------------
     v4i bh[KSH], bv;
@@ -132,13 +184,44 @@ __global__ __launch_bounds__(kThreads) void sep_mfma_kernel(const uint8_t* __res
         bv = (v4i){(int)wds[0], (int)wds[1], (int)wds[2], (int)wds[3]};
     }
 
-    // ---- 2. row pass: wave w owns column tiles t = w and w + 4 of every 16-row tile --------------------------
+    // per-lane LDS addresses (tile independent)
+    uint8_t* const st_src = s_src + lrow * PS + 16 * lch;                       // source staging: + 16 i PS
+    const uint8_t* const a_h = s_src + m * PS + 16 * gq + 16 * wave;            // row pass A: + 16 mt PS + 64 q
+    uint8_t* const w_hi = &s_ht[0][(16 * wave + m) * kPitchH + 4 * gq];         // row pass result: + 64 half kPitchH + 16 mt
+    uint8_t* const w_lo = &s_ht[1][(16 * wave + m) * kPitchH + 4 * gq];
+    const uint8_t* const a_vhi = &s_ht[0][(32 * wave + m) * kPitchH + 16 * gq]; // column pass A: + 16 mh kPitchH + 16 nt
+    const uint8_t* const a_vlo = &s_ht[1][(32 * wave + m) * kPitchH + 16 * gq];
+    uint8_t* const s_out = s_src;
+    uint8_t* const w_out = s_out + m * kPitchO + 32 * wave + 4 * gq;            // + 16 nt kPitchO + 16 mh
+    const int orow = tid >> 3, occ = tid & 7;                                   // output chunk: rows orow, orow + 32
+    const uint8_t* const r_out = s_out + orow * kPitchO + 16 * occ;
+    const unsigned ooff = (unsigned)(orow * (int)g.d_row + 16 * occ), ostep = (unsigned)(32 * (int)g.d_row);
+
     const int MT = (RY + 15) / 16;
-    for (int mt = 0; mt < MT; ++mt) {
-        const uint8_t* arow = s_src + (16 * mt + m) * PS + 16 * gq + 16 * wave;
+    int pslot = 0;
+    auto stamp = [&]() { if (g.prof && blockIdx.x == 0 && tid == 0 && pslot < 64) g.prof[pslot++] = (long long)__builtin_readcyclecounter(); };
+    stamp();
+    auto do_tile = [&](const Pos& cur, const Pos& fut, u32x4 (&nxt)[NLD]) {
+    const bool live = valid(cur);                                 // block-uniform
+    // ---- 1. source tile (fetched two tiles ago) -> LDS as signed bytes; refill the registers --------------------
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (lch < NCH && lrow + 16 * i < RY) *reinterpret_cast<u32x4*>(st_src + 16 * i * PS) = nxt[i] ^ (u32x4)(0x80808080u);
+        lds_barrier();
+    }
+    stamp();
+    if (valid(fut) && !(g.ablate & 1)) fetch(fut, nxt);
+    stamp();
+    if (!live) return;
+
+    // ---- 2. row pass: wave w owns column tiles t = w and w + 4 of every 16-row tile --------------------------
+#pragma unroll
+    for (int mt = 0; mt < kRowsS / 16; ++mt) {
+        if (mt >= MT || (g.ablate & 2)) break;
         v4i ch[KSH + 1];
 #pragma unroll
-        for (int q = 0; q <= KSH; ++q) ch[q] = lds16(arow + 64 * q);   // tile w uses ch[0..KSH), tile w+4 ch[1..KSH]
+        for (int q = 0; q <= KSH; ++q) ch[q] = lds16(a_h + 16 * mt * PS + 64 * q);   // tile w: ch[0..KSH), tile w+4: ch[1..KSH]
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             v4i acc = {0, 0, 0, 0};
@@ -146,52 +229,70 @@ __global__ __launch_bounds__(kThreads) void sep_mfma_kernel(const uint8_t* __res
             for (int ks = 0; ks < KSH; ++ks)
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ch[ks + half], bh[ks], acc, 0, 0, 0);
             // acc[i] = row 16 mt + 4 gq + i, column 16 t + m; Q8.8 value h = acc + 2^15
-            const uint32_t h0 = (uint32_t)acc[0] + 32768u, h1 = (uint32_t)acc[1] + 32768u;
-            const uint32_t h2 = (uint32_t)acc[2] + 32768u, h3 = (uint32_t)acc[3] + 32768u;
-            const uint32_t hi = (__builtin_amdgcn_perm(h1, h0, 0x0c0c0501u) | __builtin_amdgcn_perm(h3, h2, 0x05010c0cu)) ^ 0x80808080u;
+            // (h >> 8) - 128 is byte 1 of acc itself ((acc + 2^15) ^ 2^15 == acc in 16 bits); (h & 255) - 128 = byte 0 ^ 0x80
+            const uint32_t h0 = (uint32_t)acc[0], h1 = (uint32_t)acc[1], h2 = (uint32_t)acc[2], h3 = (uint32_t)acc[3];
+            const uint32_t hi = __builtin_amdgcn_perm(h1, h0, 0x0c0c0501u) | __builtin_amdgcn_perm(h3, h2, 0x05010c0cu);
             const uint32_t lo = (__builtin_amdgcn_perm(h1, h0, 0x0c0c0400u) | __builtin_amdgcn_perm(h3, h2, 0x04000c0cu)) ^ 0x80808080u;
-            const int col = 16 * (wave + 4 * half) + m;
-            *reinterpret_cast<uint32_t*>(&s_ht[0][col * kPitchH + 16 * mt + 4 * gq]) = hi;
-            *reinterpret_cast<uint32_t*>(&s_ht[1][col * kPitchH + 16 * mt + 4 * gq]) = lo;
+            *reinterpret_cast<uint32_t*>(w_hi + 64 * half * kPitchH + 16 * mt) = hi;
+            *reinterpret_cast<uint32_t*>(w_lo + 64 * half * kPitchH + 16 * mt) = lo;
         }
     }
-    __syncthreads();
+    lds_barrier();
 
+    stamp();
     // ---- 3. column pass: wave w owns column tiles 2w, 2w+1; result -> staging tile (aliases the source tile) ---
-    uint8_t* s_out = s_src;
+    if (!(g.ablate & 4))
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
-        const int mt = 2 * wave + mh;
-        const uint8_t* ahi = &s_ht[0][(16 * mt + m) * kPitchH + 16 * gq];
-        const uint8_t* alo = &s_ht[1][(16 * mt + m) * kPitchH + 16 * gq];
 #pragma unroll
         for (int nt = 0; nt < TY / 16; ++nt) {
-            const v4i z = {0, 0, 0, 0};
-            const v4i dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(ahi + 16 * nt), bv, z, 0, 0, 0);
-            const v4i dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(alo + 16 * nt), bv, z, 0, 0, 0);
+            constexpr int c0 = 32768 * 256 + 32768 + 32768;      // rounding and the two +2^15 offsets, via the accumulator
+            const v4i z = {0, 0, 0, 0}, zc = {c0, c0, c0, c0};
+            const v4i dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_vhi + 16 * mh * kPitchH + 16 * nt), bv, z, 0, 0, 0);
+            const v4i dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_vlo + 16 * mh * kPitchH + 16 * nt), bv, zc, 0, 0, 0);
             uint32_t o[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (uint32_t)(dhi[i] * 256 + dlo[i] + (32768 * 256 + 32768 + 32768));
-            // o[i] bits 16..23 = output byte of column 16 mt + 4 gq + i, row 16 nt + m
+            for (int i = 0; i < 4; ++i) o[i] = ((uint32_t)dhi[i] << 8) + (uint32_t)dlo[i];
+            // o[i] bits 16..23 = output byte of column 32 w + 16 mh + 4 gq + i, row 16 nt + m
             const uint32_t pk = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u) | __builtin_amdgcn_perm(o[3], o[2], 0x06020c0cu);
-            *reinterpret_cast<uint32_t*>(s_out + (16 * nt + m) * kPitchO + 16 * mt + 4 * gq) = pk;
+            *reinterpret_cast<uint32_t*>(w_out + 16 * nt * kPitchO + 16 * mh) = pk;
         }
     }
-    __syncthreads();
+    lds_barrier();
 
+    stamp();
     // ---- 4. staging tile -> global, 16 bytes per lane, whole 128-byte rows -----------------------------------
-    uint8_t* dimg = dst + (int64_t)img * g.d_img;
-    for (int idx = tid; idx < TY * (TX / 16); idx += kThreads) {
-        const int row = idx / (TX / 16), cc = idx % (TX / 16);
-        const int y = y0 + row, x = x0 + 16 * cc;
-        if (y >= g.h || x >= g.L) continue;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(s_out + row * kPitchO + 16 * cc);
-        uint8_t* dp = dimg + (int64_t)y * g.d_row + x;
-        if (x + 16 <= g.L) {
-            st16_nt(dp, v);
+    if (!(g.ablate & 8)) {
+        const int x0 = tile_x(cur) * TX, y0 = tile_y(cur) * TY;
+        uint8_t* dbase = dst + (int64_t)cur.img * g.d_img + (int64_t)y0 * g.d_row + x0;
+        if (g.fast32 && y0 + TY <= g.h && x0 + TX <= g.L) {       // whole tile inside (block-uniform)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+                st16_nt(dbase + (ooff + it * ostep), *reinterpret_cast<const u32x4*>(r_out + 32 * it * kPitchO));
         } else {
-            for (int b = 0; x + b < g.L; ++b) dp[b] = (uint8_t)(v[b >> 2] >> (8 * (b & 3)));
+            for (int it = 0; it < 2; ++it) {
+                const int row = orow + 32 * it, y = y0 + row, x = x0 + 16 * occ;
+                if (y >= g.h || x >= g.L) continue;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(r_out + 32 * it * kPitchO);
+                uint8_t* dp = dbase + (int64_t)row * g.d_row + 16 * occ;
+                if (x + 16 <= g.L) {
+                    st16_nt(dp, v);
+                } else {
+                    for (int b = 0; x + b < g.L; ++b) dp[b] = (uint8_t)(v[b >> 2] >> (8 * (b & 3)));
+                }
+            }
         }
+    }
+    lds_barrier();                                              // the staging tile is the next source tile
+    stamp();
+    };
+    while (pa.P < g.npatches) {
+        const Pos fa = advance(pb);
+        do_tile(pa, fa, bufa);
+        const Pos fb = advance(fa);
+        if (pb.P < g.npatches) do_tile(pb, fb, bufb);
+        pa = fa;
+        pb = fb;
     }
 }
 
@@ -199,7 +300,7 @@ template <int C>
 void launch_c(hipStream_t st, const uint8_t* src, uint8_t* dst, const MGeom& g, const MTaps& t)
 {
     const int hl = (g.r * C + 15) & ~15;
-    const dim3 grid(g.ntiles), block(kThreads);
+    const dim3 grid(8u * (unsigned)(g.pw * g.ph)), block(kThreads);
     switch (hl) {
         case 16: hipLaunchKernelGGL((sep_mfma_kernel<C, 16>), grid, block, 0, st, src, dst, g, t); break;
         case 32: hipLaunchKernelGGL((sep_mfma_kernel<C, 32>), grid, block, 0, st, src, dst, g, t); break;
@@ -222,12 +323,35 @@ int ipx_sep_mfma(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h,
     MGeom g;
     g.h = h; g.w = w; g.L = w * c; g.r = k / 2; g.K = k;
     g.s_row = s_row; g.s_img = s_img; g.d_row = d_row; g.d_img = d_img; g.top = top; g.bot = bot;
+    g.fast32 = s_row < (1 << 24) && d_row < (1 << 24) && s_row >= 0 && d_row >= 0;
     g.tiles_x = (g.L + TX - 1) / TX;
     g.tiles_y = (h + TY - 1) / TY;
+    // blocks per XCD: 96 (3 resident blocks of 52-55 KiB LDS on each of its 32 CUs), fewer for small inputs; patch
+    // shape = the divisor pair of that number that wastes the fewest tile slots, squarest first
     const uint64_t nt = (uint64_t)n * g.tiles_x * g.tiles_y;
-    if (nt > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: image too large", fn);
-    g.ntiles = (unsigned)nt;
+    int nb = 96;
+    if (const char* e = getenv("IPX_MFMA_BLOCKS")) { if (atoi(e) > 0) nb = atoi(e); }                 // dev knob
+    if ((uint64_t)nb * 8 > nt) nb = (int)((nt + 7) / 8);
+    g.pw = nb < g.tiles_x ? nb : g.tiles_x;
+    g.ph = nb / g.pw > 0 ? nb / g.pw : 1;
+    if (nb == 96) {
+        static const int cand[][2] = {{12, 8}, {8, 12}, {16, 6}, {6, 16}, {24, 4}, {4, 24}, {32, 3}, {48, 2}, {96, 1}};
+        uint64_t best = ~0ull;
+        for (const auto& cd : cand) {
+            const uint64_t padded = (uint64_t)((g.tiles_x + cd[0] - 1) / cd[0] * cd[0]) * ((g.tiles_y + cd[1] - 1) / cd[1] * cd[1]);
+            if (padded < best) { best = padded; g.pw = cd[0]; g.ph = cd[1]; }
+        }
+    }
+    g.patches_x = (g.tiles_x + g.pw - 1) / g.pw;
+    g.patches_y = (g.tiles_y + g.ph - 1) / g.ph;
+    const uint64_t np = (uint64_t)n * g.patches_x * g.patches_y;
+    if (np > 0x7ffffff0ull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: image too large", fn);
+    g.npatches = (unsigned)np;
     MTaps t{};
+    g.prof = nullptr;
+    g.ablate = getenv("IPX_MFMA_ABLATE") ? atoi(getenv("IPX_MFMA_ABLATE")) : 0;
+    const bool prof = getenv("IPX_MFMA_PROF") != nullptr;                    // dev knob: print block 0's phase stamps
+    if (prof) { IPX_HIP(hipMalloc((void**)&g.prof, 64 * sizeof(long long))); IPX_HIP(hipMemset(g.prof, 0, 64 * sizeof(long long))); }
     for (int i = 0; i < k; ++i) { t.kx[i] = (uint8_t)kx[i]; t.ky[i] = (uint8_t)ky[i]; }
     switch (c) {
         case 1: launch_c<1>(st, src, dst, g, t); break;
@@ -236,5 +360,14 @@ int ipx_sep_mfma(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h,
         default: launch_c<4>(st, src, dst, g, t); break;
     }
     IPX_LAUNCH_CHECK("sep_mfma_kernel");
+    if (prof) {
+        long long hst[64];
+        IPX_HIP(hipDeviceSynchronize());
+        IPX_HIP(hipMemcpy(hst, g.prof, sizeof(hst), hipMemcpyDeviceToHost));
+        IPX_HIP(hipFree(g.prof));
+        fprintf(stderr, "sep_mfma k=%d stamps (cycles since first):", k);
+        for (int i = 1; i < 64 && hst[i]; ++i) fprintf(stderr, " %lld", hst[i] - hst[0]);
+        fprintf(stderr, "\n");
+    }
     return IPX_OK;
 }
