@@ -5,7 +5,7 @@
 // ipx_sepbig.hip reaches ~5 % of the HBM roofline).  Both passes are banded-Toeplitz matrix products, so they go to the
 // int8 MFMA (v_mfma_i32_16x16x64_i8, exact int32 accumulation) and the whole filter becomes one HBM-bound kernel:
 //
-//   tile = 64 output rows x 128 output byte columns (interleaved channels stay interleaved; taps sit C bytes apart)
+//   tile = 64 output rows x 128 output byte columns, one 512-thread block (8 waves, one per 16-column slice) (interleaved channels stay interleaved; taps sit C bytes apart)
 //   1. the (64 + 2r) x (128 + 2 HL) source tile goes to LDS as signed bytes (u - 128), REFLECT_101 / halo rows applied
 //   2. row pass     H[y][x]  = sum_k S[y][x - HL + k] * Tx[k][x']      A = S rows (ds_read_b128), B = Toeplitz(kx), the
 //                                                                     SAME B registers for every tile (shift invariance)
@@ -29,9 +29,12 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int TY = 64, TX = 128, kThreads = 256;
-constexpr int kRowsS = 96;                       // 6 M-tiles of source rows (64 + 2*15 = 94 used at most)
-constexpr int kPitchH = 112;                     // bytes per HT column: >= 96, >= TY - 16 + 64, pitch/4 = 4 mod 8
+constexpr int TY = 64, TX = 128, kThreads = 512;       // 8 waves per tile: 3 resident blocks = 24 waves per CU
+constexpr int kRowsS = 96;                       // 6 M-tiles of source rows (64 + 2*15 = 94 exist at most)
+constexpr int kPitchH = 96;                      // bytes per HT column = the 96 row-pass rows; 32 mod 64 makes the column
+                                                 // pass's ds_read_b128 conflict-free (lane groups of MI355X_MICROARCH.md
+                                                 // section LDS).  Its last k-chunk (rows 96..111, zero taps) reads on into
+                                                 // the next column / the bytes behind the plane: finite garbage times zero
 constexpr int kPitchO = 144;                     // result staging pitch (pitch/4 = 4 mod 8, multiple of 16)
 
 struct MGeom {
@@ -62,17 +65,22 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ v4i lds16(const uint8_t* p) { return *reinterpret_cast<const v4i*>(p); }
 
 template <int C, int HL>
-__global__ __launch_bounds__(kThreads, 2) void sep_mfma_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+__global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                MGeom g, MTaps taps)
 {
     constexpr int KSH = (16 + 2 * HL + 63) / 64;                 // k-steps of the row pass
     constexpr int SW = TX + 2 * HL;                              // source tile width in bytes
-    constexpr int PS = HL <= 48 ? 240 : 272;                     // source pitch: >= SW, = 16 or 240 mod 256
+    constexpr int PS = HL <= 48 ? 224 : 288;                     // source pitch: >= SW and = 32 mod 64: conflict-free b128 reads
     constexpr int NCH = SW / 16;
-    constexpr int NLD = kRowsS / 16;                             // source rows per thread: rows (tid >> 4) + 16 i
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[kRowsS * PS + 64 * KSH];   // also the result staging tile
-    __shared__ __attribute__((aligned(16))) uint8_t s_ht[2][TX * kPitchH];
-    __shared__ uint8_t s_taps[64];
+    constexpr int NLD = kRowsS / 32;                             // source rows per thread: rows (tid >> 4) + 32 i
+    // one LDS block: source tile (also the result staging tile) | the two transposed planes | taps.  Only TY + 30 = 94
+    // source rows exist; the row pass's last 16-row tile and its k-step padding read on into the planes (times zero taps)
+    constexpr int kSrcBytes = (TY + 30) * PS;
+    __shared__ __attribute__((aligned(16))) uint8_t s_all[kSrcBytes + 2 * TX * kPitchH + 64 + 16];
+    uint8_t* const s_src = s_all;
+    uint8_t* const s_ht0 = s_all + kSrcBytes;
+    uint8_t* const s_ht1 = s_ht0 + TX * kPitchH;
+    uint8_t* const s_taps = s_ht1 + TX * kPitchH;
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, gq = lane >> 4;
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(kThreads, 2) void sep_mfma_kernel(const uint8_t* __
 
     // Blocks b, b + 8, b + 16, ... share an XCD (round-robin dispatch), so block b = 8 q + x is tile q of the pw x ph
     // patch that XCD x works on; the XCD walks patches x, x + 8, x + 16, ...  Neighbouring tiles of a patch are in
-    // flight together and share their halos through that XCD's L2.  The next TWO tiles of a block are prefetched into
+    // flight together and share their halos through that XCD's L2.  The next tile of a block is prefetched into
     // registers while the current one is filtered.  Patch coordinates advance incrementally (no divisions per tile).
     struct Pos { int ppx, ppy; unsigned img, P; };
     const int q = (int)(blockIdx.x >> 3), qx = q % g.pw, qy = q / g.pw;
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(kThreads, 2) void sep_mfma_kernel(const uint8_t* __
     unsigned loff[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i)
-        loff[i] = (unsigned)((lrow + 16 * i < RY ? lrow + 16 * i : RY - 1) * (int)g.s_row + 16 * (lch < NCH ? lch : NCH - 1));
+        loff[i] = (unsigned)((lrow + 32 * i < RY ? lrow + 32 * i : RY - 1) * (int)g.s_row + 16 * (lch < NCH ? lch : NCH - 1));
 
     auto fetch = [&](const Pos& p, u32x4 (&reg)[NLD]) {
         const uint8_t* simg = src + (int64_t)p.img * g.s_img;
@@ -122,25 +130,28 @@ __global__ __launch_bounds__(kThreads, 2) void sep_mfma_kernel(const uint8_t* __
         const bool xin = xs0 >= 0 && xs0 + SW <= g.L;            // block-uniform
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int row = lrow + 16 * i < RY ? lrow + 16 * i : RY - 1;
+            const int row = lrow + 32 * i < RY ? lrow + 32 * i : RY - 1;
             int ys = ys0 + row;
             if (ys > g.h + r - 1) ys = g.h + r - 1;                 // rows below the last one anybody needs: clamp
             const uint8_t* rp = src_row(g, simg, ys);
             if (xin) {
                 reg[i] = ld16(rp + gx);
-            } else {
-                int off[16];
+            } else {                                              // 4 x 4 byte loads; kept apart so that this rare path
+                uint32_t wds[4];                                  // does not raise the kernel's register count
 #pragma unroll
-                for (int b = 0; b < 16; ++b) {
-                    const int col = gx + b;
-                    int px = col >= 0 ? col / C : -((-col + C - 1) / C);
-                    const int chn = col - px * C;
-                    px = px < -r ? -r : px > g.w - 1 + r ? g.w - 1 + r : px;   // further out: never used, keep it cheap
-                    off[b] = reflect101(px, g.w) * C + chn;
+                for (int wd = 0; wd < 4; ++wd) {
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int col = gx + 4 * wd + b;
+                        int px = col >= 0 ? col / C : -((-col + C - 1) / C);
+                        const int chn = col - px * C;
+                        px = px < -r ? -r : px > g.w - 1 + r ? g.w - 1 + r : px;   // further out: never used
+                        word |= (uint32_t)rp[reflect101(px, g.w) * C + chn] << (8 * b);
+                    }
+                    wds[wd] = word;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                uint32_t wds[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int b = 0; b < 16; ++b) wds[b >> 2] |= (uint32_t)rp[off[b]] << (8 * (b & 3));
                 reg[i] = (u32x4){wds[0], wds[1], wds[2], wds[3]};
             }
         }
@@ -150,10 +161,8 @@ __global__ __launch_bounds__(kThreads, 2) void sep_mfma_kernel(const uint8_t* __
     pa.ppx = (int)(pa.P % (unsigned)g.patches_x);
     pa.ppy = (int)(pa.P / (unsigned)g.patches_x % (unsigned)g.patches_y);
     pa.img = pa.P / ((unsigned)g.patches_x * (unsigned)g.patches_y);
-    Pos pb = advance(pa);
-    u32x4 bufa[NLD], bufb[NLD];
+    u32x4 bufa[NLD];
     if (valid(pa)) fetch(pa, bufa);
-    if (valid(pb)) fetch(pb, bufb);
     __syncthreads();                                              // s_taps
 
     // ---- Toeplitz operands (registers, the same for every tile) ----------------------------------------------
@@ -185,17 +194,18 @@ __global__ __launch_bounds__(kThreads, 2) void sep_mfma_kernel(const uint8_t* __
     }
 
     // per-lane LDS addresses (tile independent)
-    uint8_t* const st_src = s_src + lrow * PS + 16 * lch;                       // source staging: + 16 i PS
+    uint8_t* const st_src = s_src + lrow * PS + 16 * lch;                       // source staging: + 32 i PS
     const uint8_t* const a_h = s_src + m * PS + 16 * gq + 16 * wave;            // row pass A: + 16 mt PS + 64 q
-    uint8_t* const w_hi = &s_ht[0][(16 * wave + m) * kPitchH + 4 * gq];         // row pass result: + 64 half kPitchH + 16 mt
-    uint8_t* const w_lo = &s_ht[1][(16 * wave + m) * kPitchH + 4 * gq];
-    const uint8_t* const a_vhi = &s_ht[0][(32 * wave + m) * kPitchH + 16 * gq]; // column pass A: + 16 mh kPitchH + 16 nt
-    const uint8_t* const a_vlo = &s_ht[1][(32 * wave + m) * kPitchH + 16 * gq];
+    constexpr int swz = 0;
+    uint8_t* const w_hi = s_ht0 + (16 * wave + m) * kPitchH + 4 * gq;           // row pass result: + 16 (mt ^ swz)
+    uint8_t* const w_lo = s_ht1 + (16 * wave + m) * kPitchH + 4 * gq;
+    const uint8_t* const a_vhi = s_ht0 + (16 * wave + m) * kPitchH;             // column pass A: + 16 ((nt + gq) ^ swz)
+    const uint8_t* const a_vlo = s_ht1 + (16 * wave + m) * kPitchH;
     uint8_t* const s_out = s_src;
-    uint8_t* const w_out = s_out + m * kPitchO + 32 * wave + 4 * gq;            // + 16 nt kPitchO + 16 mh
-    const int orow = tid >> 3, occ = tid & 7;                                   // output chunk: rows orow, orow + 32
+    uint8_t* const w_out = s_out + m * kPitchO + 16 * wave + 4 * gq;            // + 16 nt kPitchO
+    const int orow = tid >> 3, occ = tid & 7;                                   // output chunk: row orow (0..63)
     const uint8_t* const r_out = s_out + orow * kPitchO + 16 * occ;
-    const unsigned ooff = (unsigned)(orow * (int)g.d_row + 16 * occ), ostep = (unsigned)(32 * (int)g.d_row);
+    const unsigned ooff = (unsigned)(orow * (int)g.d_row + 16 * occ);
 
     const int MT = (RY + 15) / 16;
     int pslot = 0;
@@ -203,11 +213,11 @@ __global__ __launch_bounds__(kThreads, 2) void sep_mfma_kernel(const uint8_t* __
     stamp();
     auto do_tile = [&](const Pos& cur, const Pos& fut, u32x4 (&nxt)[NLD]) {
     const bool live = valid(cur);                                 // block-uniform
-    // ---- 1. source tile (fetched two tiles ago) -> LDS as signed bytes; refill the registers --------------------
+    // ---- 1. source tile (fetched during the previous tile) -> LDS as signed bytes; refill the registers --------
     if (live) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (lch < NCH && lrow + 16 * i < RY) *reinterpret_cast<u32x4*>(st_src + 16 * i * PS) = nxt[i] ^ (u32x4)(0x80808080u);
+            if (lch < NCH && lrow + 32 * i < RY) *reinterpret_cast<u32x4*>(st_src + 32 * i * PS) = nxt[i] ^ (u32x4)(0x80808080u);
         lds_barrier();
     }
     stamp();
@@ -215,48 +225,40 @@ __global__ __launch_bounds__(kThreads, 2) void sep_mfma_kernel(const uint8_t* __
     stamp();
     if (!live) return;
 
-    // ---- 2. row pass: wave w owns column tiles t = w and w + 4 of every 16-row tile --------------------------
+    // ---- 2. row pass: wave w owns column tile w (16 output columns) of every 16-row tile ----------------------
 #pragma unroll
     for (int mt = 0; mt < kRowsS / 16; ++mt) {
         if (mt >= MT || (g.ablate & 2)) break;
-        v4i ch[KSH + 1];
+        v4i acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q <= KSH; ++q) ch[q] = lds16(a_h + 16 * mt * PS + 64 * q);   // tile w: ch[0..KSH), tile w+4: ch[1..KSH]
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            v4i acc = {0, 0, 0, 0};
-#pragma unroll
-            for (int ks = 0; ks < KSH; ++ks)
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ch[ks + half], bh[ks], acc, 0, 0, 0);
-            // acc[i] = row 16 mt + 4 gq + i, column 16 t + m; Q8.8 value h = acc + 2^15
-            // (h >> 8) - 128 is byte 1 of acc itself ((acc + 2^15) ^ 2^15 == acc in 16 bits); (h & 255) - 128 = byte 0 ^ 0x80
-            const uint32_t h0 = (uint32_t)acc[0], h1 = (uint32_t)acc[1], h2 = (uint32_t)acc[2], h3 = (uint32_t)acc[3];
-            const uint32_t hi = __builtin_amdgcn_perm(h1, h0, 0x0c0c0501u) | __builtin_amdgcn_perm(h3, h2, 0x05010c0cu);
-            const uint32_t lo = (__builtin_amdgcn_perm(h1, h0, 0x0c0c0400u) | __builtin_amdgcn_perm(h3, h2, 0x04000c0cu)) ^ 0x80808080u;
-            *reinterpret_cast<uint32_t*>(w_hi + 64 * half * kPitchH + 16 * mt) = hi;
-            *reinterpret_cast<uint32_t*>(w_lo + 64 * half * kPitchH + 16 * mt) = lo;
-        }
+        for (int ks = 0; ks < KSH; ++ks)
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_h + 16 * mt * PS + 64 * ks), bh[ks], acc, 0, 0, 0);
+        // acc[i] = row 16 mt + 4 gq + i, column 16 w + m; Q8.8 value h = acc + 2^15
+        // (h >> 8) - 128 is byte 1 of acc itself ((acc + 2^15) ^ 2^15 == acc in 16 bits); (h & 255) - 128 = byte 0 ^ 0x80
+        const uint32_t h0 = (uint32_t)acc[0], h1 = (uint32_t)acc[1], h2 = (uint32_t)acc[2], h3 = (uint32_t)acc[3];
+        const uint32_t hi = __builtin_amdgcn_perm(h1, h0, 0x0c0c0501u) | __builtin_amdgcn_perm(h3, h2, 0x05010c0cu);
+        const uint32_t lo = (__builtin_amdgcn_perm(h1, h0, 0x0c0c0400u) | __builtin_amdgcn_perm(h3, h2, 0x04000c0cu)) ^ 0x80808080u;
+        *reinterpret_cast<uint32_t*>(w_hi + 16 * (mt ^ swz)) = hi;
+        *reinterpret_cast<uint32_t*>(w_lo + 16 * (mt ^ swz)) = lo;
     }
     lds_barrier();
 
     stamp();
-    // ---- 3. column pass: wave w owns column tiles 2w, 2w+1; result -> staging tile (aliases the source tile) ---
+    // ---- 3. column pass: wave w owns column tile w; result -> staging tile (aliases the source tile) ----------
     if (!(g.ablate & 4))
 #pragma unroll
-    for (int mh = 0; mh < 2; ++mh) {
+    for (int nt = 0; nt < TY / 16; ++nt) {
+        constexpr int c0 = 32768 * 256 + 32768 + 32768;          // rounding and the two +2^15 offsets, via the accumulator
+        const v4i z = {0, 0, 0, 0}, zc = {c0, c0, c0, c0};
+        const int vo = 16 * ((nt + gq) ^ swz);
+        const v4i dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_vhi + vo), bv, z, 0, 0, 0);
+        const v4i dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_vlo + vo), bv, zc, 0, 0, 0);
+        uint32_t o[4];
 #pragma unroll
-        for (int nt = 0; nt < TY / 16; ++nt) {
-            constexpr int c0 = 32768 * 256 + 32768 + 32768;      // rounding and the two +2^15 offsets, via the accumulator
-            const v4i z = {0, 0, 0, 0}, zc = {c0, c0, c0, c0};
-            const v4i dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_vhi + 16 * mh * kPitchH + 16 * nt), bv, z, 0, 0, 0);
-            const v4i dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_vlo + 16 * mh * kPitchH + 16 * nt), bv, zc, 0, 0, 0);
-            uint32_t o[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = ((uint32_t)dhi[i] << 8) + (uint32_t)dlo[i];
-            // o[i] bits 16..23 = output byte of column 32 w + 16 mh + 4 gq + i, row 16 nt + m
-            const uint32_t pk = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u) | __builtin_amdgcn_perm(o[3], o[2], 0x06020c0cu);
-            *reinterpret_cast<uint32_t*>(w_out + 16 * nt * kPitchO + 16 * mh) = pk;
-        }
+        for (int i = 0; i < 4; ++i) o[i] = ((uint32_t)dhi[i] << 8) + (uint32_t)dlo[i];
+        // o[i] bits 16..23 = output byte of column 16 w + 4 gq + i, row 16 nt + m
+        const uint32_t pk = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u) | __builtin_amdgcn_perm(o[3], o[2], 0x06020c0cu);
+        *reinterpret_cast<uint32_t*>(w_out + 16 * nt * kPitchO) = pk;
     }
     lds_barrier();
 
@@ -266,15 +268,12 @@ __global__ __launch_bounds__(kThreads, 2) void sep_mfma_kernel(const uint8_t* __
         const int x0 = tile_x(cur) * TX, y0 = tile_y(cur) * TY;
         uint8_t* dbase = dst + (int64_t)cur.img * g.d_img + (int64_t)y0 * g.d_row + x0;
         if (g.fast32 && y0 + TY <= g.h && x0 + TX <= g.L) {       // whole tile inside (block-uniform)
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-                st16_nt(dbase + (ooff + it * ostep), *reinterpret_cast<const u32x4*>(r_out + 32 * it * kPitchO));
+            st16_nt(dbase + ooff, *reinterpret_cast<const u32x4*>(r_out));
         } else {
-            for (int it = 0; it < 2; ++it) {
-                const int row = orow + 32 * it, y = y0 + row, x = x0 + 16 * occ;
-                if (y >= g.h || x >= g.L) continue;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(r_out + 32 * it * kPitchO);
-                uint8_t* dp = dbase + (int64_t)row * g.d_row + 16 * occ;
+            const int y = y0 + orow, x = x0 + 16 * occ;
+            if (y < g.h && x < g.L) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(r_out);
+                uint8_t* dp = dbase + (int64_t)orow * g.d_row + 16 * occ;
                 if (x + 16 <= g.L) {
                     st16_nt(dp, v);
                 } else {
@@ -287,12 +286,9 @@ __global__ __launch_bounds__(kThreads, 2) void sep_mfma_kernel(const uint8_t* __
     stamp();
     };
     while (pa.P < g.npatches) {
-        const Pos fa = advance(pb);
+        const Pos fa = advance(pa);
         do_tile(pa, fa, bufa);
-        const Pos fb = advance(fa);
-        if (pb.P < g.npatches) do_tile(pb, fb, bufb);
         pa = fa;
-        pb = fb;
     }
 }
 
