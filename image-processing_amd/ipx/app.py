@@ -79,132 +79,174 @@ def create_app(backend=None) -> Flask:
             state["backend"] = GpuBackend()
         return state["backend"]
 
-    @app.route("/api/process", methods=["POST"])
-    def api_process():
-        f = request.files.get("file")
-        mode = request.form.get("mode", "gray8")
-        if not f:
-            return jsonify({"error": "missing file"}), 400
-        try:
-            data = f.read()
-            params = {}
-            b = be()
+    def batch_backends():
+        """One backend per visible GPU for /api/process_batch (an injected test backend is used as is)."""
+        if state.get("pool") is None:
+            if backend is not None:
+                state["pool"] = [backend]
+            else:
+                import torch
+                n = max(1, torch.cuda.device_count())
+                state["pool"] = [be()] + [GpuBackend(f"cuda:{i}") for i in range(1, n)]
+        return state["pool"]
 
-            if mode in OUT_OF_SCOPE:
-                return jsonify({"error": f"mode '{mode}' is outside the GPU hot path of this backend "
-                                         "(convolution filters, histogram equalization, pixel-wise transforms)"}), 501
+    def process_one(b, data: bytes, form):
+        """One image through the reference's dispatch (server.py:22-472): returns (payload dict, HTTP status)."""
+        mode = form.get("mode", "gray8")
+        params = {}
 
-            if mode == "denoise_manual":                                # server.py:181-241; method=lee runs on the GPU
-                img = ensure_gray_uint8(b, data)
-                method_name = request.form.get("method", "median")
-                kernel = int(request.form.get("kernel", "5"))
-                if kernel % 2 == 0:
-                    kernel += 1
-                kernel = max(3, min(31, kernel))
-                if method_name != "lee":                                 # every other branch is a cv2 filter (C10)
-                    return jsonify({"error": f"denoise_manual method '{method_name}' is outside the GPU hot path of this "
-                                             "backend (only method=lee is built: SURVEY.md section 8(f))"}), 501
-                # histogram analysis (server.py:190-211) from the GPU's exact 256-bin histogram, Lee filter on the GPU
-                hist, img_denoised = b.run(lambda ops, t: (ops.hist(t), ops.lee_filter(t, kernel)), img)
-                st = b.stats_from_hist(hist, method_name)
-                method = f"Lee Filter (w={kernel})"
-                params = {"method": method, "kernel": kernel,
-                          "histogram": {"extreme_ratio": round(st["extreme_ratio"], 4), "variance": round(st["variance"], 2),
-                                        "cv": round(st["cv"], 4), "suggested_method": st["suggested_method"]}}
-                return jsonify({"dataURL": codec.to_data_url_png(img_denoised), "message": f"Manual denoise: {method}",
-                                "params": params}), 200
+        if mode in OUT_OF_SCOPE:
+            return {"error": f"mode '{mode}' is outside the GPU hot path of this backend "
+                                     "(convolution filters, histogram equalization, pixel-wise transforms)"}, 501
 
-            if mode == "histogram_eq":                                  # server.py:243-248
-                img = codec.decode_unchanged(data)
-                if img.ndim == 3:                                        # colour: gray + histogram in one pass
-                    img_eq = b.run(lambda ops, t: ops.bgr2gray_equalize(t)[1], img)
-                else:
-                    if img.dtype == np.uint16:
-                        img = (img >> 8).astype(np.uint8)
-                    img_eq = b.run(lambda ops, t: ops.equalize_hist(t), img)
-                params = {"method": "Histogram Equalization"}
-                return jsonify({"dataURL": codec.to_data_url_png(img_eq), "message": "Histogram Equalized", "params": params}), 200
+        if mode == "denoise_manual":                                # server.py:181-241; method=lee runs on the GPU
+            img = ensure_gray_uint8(b, data)
+            method_name = form.get("method", "median")
+            kernel = int(form.get("kernel", "5"))
+            if kernel % 2 == 0:
+                kernel += 1
+            kernel = max(3, min(31, kernel))
+            if method_name != "lee":                                 # every other branch is a cv2 filter (C10)
+                return {"error": f"denoise_manual method '{method_name}' is outside the GPU hot path of this "
+                                         "backend (only method=lee is built: SURVEY.md section 8(f))"}, 501
+            # histogram analysis (server.py:190-211) from the GPU's exact 256-bin histogram, Lee filter on the GPU
+            hist, img_denoised = b.run(lambda ops, t: (ops.hist(t), ops.lee_filter(t, kernel)), img)
+            st = b.stats_from_hist(hist, method_name)
+            method = f"Lee Filter (w={kernel})"
+            params = {"method": method, "kernel": kernel,
+                      "histogram": {"extreme_ratio": round(st["extreme_ratio"], 4), "variance": round(st["variance"], 2),
+                                    "cv": round(st["cv"], 4), "suggested_method": st["suggested_method"]}}
+            return {"dataURL": codec.to_data_url_png(img_denoised), "message": f"Manual denoise: {method}",
+                            "params": params}, 200
 
-            if mode == "sharpening":                                    # server.py:250-283
-                img = codec.decode_color(data)
-                if img is None:
-                    img = ensure_gray_uint8(b, data)
-                    is_color = False
-                else:
-                    is_color = True
-                sharp_type = request.form.get("sharp_type", "laplacian")
-                if sharp_type == "laplacian":
-                    img_sharp = b.run(lambda ops, t: ops.laplacian_sharpen(t), img)
-                    method = "Laplacian"
-                else:
-                    img_sharp = img
-                    method = "No sharpening"
-                params = {"method": method, "color": is_color}
-                return jsonify({"dataURL": codec.to_data_url_png(img_sharp), "message": f"Sharpened: {method}", "params": params}), 200
-
-            if mode == "pca":                                           # server.py:353-356
-                return jsonify({"error": "mode 'pca' has been removed on server. Use 'pca_nn' for PCA+NN inference "
-                                         "or 'detect' for object detection."}), 400
-
-            if mode in ("gaussian", "box", "sobel"):                    # extension modes (not in the reference)
-                img = codec.decode_unchanged(data)
+        if mode == "histogram_eq":                                  # server.py:243-248
+            img = codec.decode_unchanged(data)
+            if img.ndim == 3:                                        # colour: gray + histogram in one pass
+                img_eq = b.run(lambda ops, t: ops.bgr2gray_equalize(t)[1], img)
+            else:
                 if img.dtype == np.uint16:
                     img = (img >> 8).astype(np.uint8)
-                if img.ndim == 3 and img.shape[2] == 4:
-                    img = np.ascontiguousarray(img[:, :, :3])
-                if mode == "gaussian":
-                    k = int(request.form.get("k", "5"))
-                    if k % 2 == 0:
-                        k += 1
-                    k = max(1, min(255, k))
-                    out = b.run(lambda ops, t: ops.gaussian_blur(t, k), img)
-                    params = {"ksize": k}
-                elif mode == "box":
-                    out = b.run(lambda ops, t: ops.box3(t), img)
-                else:
-                    out = b.run(lambda ops, t: ops.sobel(t), img)
-                return jsonify({"dataURL": codec.to_data_url_png(out), "message": "ok", "params": params}), 200
+                img_eq = b.run(lambda ops, t: ops.equalize_hist(t), img)
+            params = {"method": "Histogram Equalization"}
+            return {"dataURL": codec.to_data_url_png(img_eq), "message": "Histogram Equalized", "params": params}, 200
 
-            # every other mode works on grayscale (server.py:358-360); unknown modes return plain gray
-            lut = None
-            if mode in ("gamma", "powerlaw", "power-law"):              # server.py:362-373
-                gamma_param = request.form.get("gamma") or request.form.get("gamma_value") or request.form.get("g")
-                if gamma_param is None:
-                    return jsonify({"error": "Missing required parameter: gamma"}), 400
-                gamma_val = float(gamma_param)
-                lut = luts.gamma(gamma_val)
-                params = {"gamma": float(gamma_val)}
-            elif mode == "negative":                                    # server.py:375-376
-                lut = luts.negative()
-            elif mode == "threshold":                                   # server.py:378-381
-                T = int(request.form.get("threshold") or request.form.get("T") or 128)
-                lut = luts.threshold(T)
-                params["threshold"] = T
-            elif mode in ("piecewise", "piecewise_linear", "stretch"):  # server.py:443-469
-                if not all(k in request.form for k in ["r1", "s1", "r2", "s2"]):
-                    return jsonify({"error": "Missing required parameters: r1, s1, r2, s2"}), 400
-                r1, s1, r2, s2 = luts.piecewise_clamp(int(request.form.get("r1")), int(request.form.get("s1")),
-                                                      int(request.form.get("r2")), int(request.form.get("s2")))
-                lut = luts.piecewise(r1, s1, r2, s2)
-                params = {"r1": r1, "s1": s1, "r2": r2, "s2": s2}
-
-            img = codec.decode_unchanged(data)
-            is_log = mode in ("log", "logarithmic", "logrithmic")       # server.py:383-388
-            if is_log:
-                c_val = float(request.form.get("c", "2.0"))
-                gray = ensure_gray_uint8(b, data) if img.ndim == 3 or img.dtype != np.uint8 else img
-                hist = b.run(lambda ops, t: ops.hist(t), gray)           # s.max() needs the levels present
-                out = b.run(lambda ops, t: ops.apply_lut(t, luts.log(c_val, hist)), gray)
-            elif lut is not None and img.ndim == 3:
-                out = b.run(lambda ops, t: ops.bgr2gray_lut(t, lut), img)   # gray + table in one pass
+        if mode == "sharpening":                                    # server.py:250-283
+            img = codec.decode_color(data)
+            if img is None:
+                img = ensure_gray_uint8(b, data)
+                is_color = False
             else:
-                gray = ensure_gray_uint8(b, data) if img.ndim == 3 or img.dtype != np.uint8 else img
-                out = gray if lut is None else b.run(lambda ops, t: ops.apply_lut(t, lut), gray)
-            return jsonify({"dataURL": codec.to_data_url_png(out), "message": "ok", "params": params}), 200
+                is_color = True
+            sharp_type = form.get("sharp_type", "laplacian")
+            if sharp_type == "laplacian":
+                img_sharp = b.run(lambda ops, t: ops.laplacian_sharpen(t), img)
+                method = "Laplacian"
+            else:
+                img_sharp = img
+                method = "No sharpening"
+            params = {"method": method, "color": is_color}
+            return {"dataURL": codec.to_data_url_png(img_sharp), "message": f"Sharpened: {method}", "params": params}, 200
+
+        if mode == "pca":                                           # server.py:353-356
+            return {"error": "mode 'pca' has been removed on server. Use 'pca_nn' for PCA+NN inference "
+                                     "or 'detect' for object detection."}, 400
+
+        if mode in ("gaussian", "box", "sobel"):                    # extension modes (not in the reference)
+            img = codec.decode_unchanged(data)
+            if img.dtype == np.uint16:
+                img = (img >> 8).astype(np.uint8)
+            if img.ndim == 3 and img.shape[2] == 4:
+                img = np.ascontiguousarray(img[:, :, :3])
+            if mode == "gaussian":
+                k = int(form.get("k", "5"))
+                if k % 2 == 0:
+                    k += 1
+                k = max(1, min(255, k))
+                out = b.run(lambda ops, t: ops.gaussian_blur(t, k), img)
+                params = {"ksize": k}
+            elif mode == "box":
+                out = b.run(lambda ops, t: ops.box3(t), img)
+            else:
+                out = b.run(lambda ops, t: ops.sobel(t), img)
+            return {"dataURL": codec.to_data_url_png(out), "message": "ok", "params": params}, 200
+
+        # every other mode works on grayscale (server.py:358-360); unknown modes return plain gray
+        lut = None
+        if mode in ("gamma", "powerlaw", "power-law"):              # server.py:362-373
+            gamma_param = form.get("gamma") or form.get("gamma_value") or form.get("g")
+            if gamma_param is None:
+                return {"error": "Missing required parameter: gamma"}, 400
+            gamma_val = float(gamma_param)
+            lut = luts.gamma(gamma_val)
+            params = {"gamma": float(gamma_val)}
+        elif mode == "negative":                                    # server.py:375-376
+            lut = luts.negative()
+        elif mode == "threshold":                                   # server.py:378-381
+            T = int(form.get("threshold") or form.get("T") or 128)
+            lut = luts.threshold(T)
+            params["threshold"] = T
+        elif mode in ("piecewise", "piecewise_linear", "stretch"):  # server.py:443-469
+            if not all(k in form for k in ["r1", "s1", "r2", "s2"]):
+                return {"error": "Missing required parameters: r1, s1, r2, s2"}, 400
+            r1, s1, r2, s2 = luts.piecewise_clamp(int(form.get("r1")), int(form.get("s1")),
+                                                  int(form.get("r2")), int(form.get("s2")))
+            lut = luts.piecewise(r1, s1, r2, s2)
+            params = {"r1": r1, "s1": s1, "r2": r2, "s2": s2}
+
+        img = codec.decode_unchanged(data)
+        is_log = mode in ("log", "logarithmic", "logrithmic")       # server.py:383-388
+        if is_log:
+            c_val = float(form.get("c", "2.0"))
+            gray = ensure_gray_uint8(b, data) if img.ndim == 3 or img.dtype != np.uint8 else img
+            hist = b.run(lambda ops, t: ops.hist(t), gray)           # s.max() needs the levels present
+            out = b.run(lambda ops, t: ops.apply_lut(t, luts.log(c_val, hist)), gray)
+        elif lut is not None and img.ndim == 3:
+            out = b.run(lambda ops, t: ops.bgr2gray_lut(t, lut), img)   # gray + table in one pass
+        else:
+            gray = ensure_gray_uint8(b, data) if img.ndim == 3 or img.dtype != np.uint8 else img
+            out = gray if lut is None else b.run(lambda ops, t: ops.apply_lut(t, lut), gray)
+        return {"dataURL": codec.to_data_url_png(out), "message": "ok", "params": params}, 200
+
+    def guarded(b, data, form):
+        try:
+            return process_one(b, data, form)
         except Exception as e:                                          # server.py:473-476
             import traceback
             traceback.print_exc()
-            return jsonify({"error": str(e)}), 500
+            return {"error": str(e)}, 500
+
+    @app.route("/api/process", methods=["POST"])
+    def api_process():
+        f = request.files.get("file")
+        if not f:
+            return jsonify({"error": "missing file"}), 400
+        payload, status = guarded(be(), f.read(), request.form)
+        return jsonify(payload), status
+
+    @app.route("/api/process_batch", methods=["POST"])
+    def api_process_batch():
+        """the same dispatch for MANY files in one request (the browser path is capped
+        at one 8 MB upload, src/app.js:548-552).  multipart: file=<f0>, file=<f1>, ... plus the form fields of
+        /api/process (applied to every file).  Image i runs on backend i mod G (one backend per visible GPU, one host
+        thread per backend); results come back in input order:
+        200 {'results': [{'status': int, 'dataURL'|'error': ..., 'message': ..., 'params': ...}, ...], 'count': n}."""
+        files = request.files.getlist("file")
+        if not files:
+            return jsonify({"error": "missing file"}), 400
+        blobs = [f.read() for f in files]
+        form = request.form
+        bes = batch_backends()
+        results = [None] * len(blobs)
+
+        def work(k):
+            for i in range(k, len(blobs), len(bes)):
+                payload, status = guarded(bes[k], blobs[i], form)
+                results[i] = dict(payload, status=status)
+
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(min(len(bes), len(blobs)))]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        return jsonify({"results": results, "count": len(results)}), 200
 
     return app
 

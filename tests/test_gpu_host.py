@@ -20,6 +20,7 @@ def test_opencv_backed_modes_on_gpu_backend(dev):
     client = app_mod.create_app(backend=app_mod.GpuBackend("cuda:0")).test_client()
     T.test_opencv_backed_modes_contract(client)
     T.test_extension_modes(client)
+    T.test_batch_endpoint(client)
 
 
 def test_batch_sharder_two_workers_one_gpu(dev):

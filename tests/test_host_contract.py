@@ -119,6 +119,26 @@ def test_out_of_scope_modes_say_so(client):
     assert r.status_code == 500 and "Cannot decode image" in r.get_json()["error"]
 
 
+def test_batch_endpoint(client):
+    """/api/process_batch: same dispatch per file, results in input order, per-file status."""
+    rng = np.random.default_rng(4)
+    imgs = [rng.integers(0, 256, (20 + i, 30, 3), dtype=np.uint8) for i in range(5)]
+    data = {"mode": "sharpening", "file": [(io.BytesIO(png(a)), f"{i}.png") for i, a in enumerate(imgs)]}
+    r = client.post("/api/process_batch", data=data, content_type="multipart/form-data")
+    js = r.get_json()
+    assert r.status_code == 200 and js["count"] == 5
+    for a, res in zip(imgs, js["results"]):
+        assert res["status"] == 200 and res["message"] == "Sharpened: Laplacian"
+        np.testing.assert_array_equal(codec.from_data_url_png(res["dataURL"]), O.laplacian_sharpen_u8(a[:, :, ::-1]))
+    data = {"mode": "gamma", "file": [(io.BytesIO(png(imgs[0])), "a.png"), (io.BytesIO(b"junk"), "b.png")]}
+    js = client.post("/api/process_batch", data=data, content_type="multipart/form-data").get_json()
+    assert [x["status"] for x in js["results"]] == [400, 400]            # gamma missing -> 400 each (server.py:365)
+    data = {"mode": "negative", "file": [(io.BytesIO(png(imgs[0])), "a.png"), (io.BytesIO(b"junk"), "b.png")]}
+    js = client.post("/api/process_batch", data=data, content_type="multipart/form-data").get_json()
+    assert [x["status"] for x in js["results"]] == [200, 500] and "Cannot decode" in js["results"][1]["error"]
+    assert client.post("/api/process_batch", data={"mode": "negative"}, content_type="multipart/form-data").status_code == 400
+
+
 def test_extension_modes(client):
     rng = np.random.default_rng(1)
     rgb = rng.integers(0, 256, (30, 44, 3), dtype=np.uint8)
