@@ -248,7 +248,18 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void conv3_kernel(const uin
 }
 
 // ---- separable fixed-point filter, K <= 7, register sliding window ---------------------------------------
-template <int K> struct Taps { uint32_t kx[K]; uint32_t ky[K]; };
+// Column pass on ROW PAIRS: the Q8.8 row results of source rows (2p, 2p+1) of the walk are re-packed (2 v_perm per
+// slot) into registers that hold the SAME column of both rows, so that one v_dot2_u32_u16 applies two taps.  The two
+// output rows 2j and 2j+1 need the same (K+1)/2 pairs, with the taps shifted by one row:
+//   even:  (ky0,ky1) (ky2,ky3) ... (ky[K-1],0)          odd:  (0,ky0) (ky1,ky2) ... (ky[K-2],ky[K-1])
+// i.e. (K+1)/2 instructions per output byte instead of K multiply-adds.
+template <int K> struct Taps { uint32_t kx[K]; uint32_t ce[(K + 1) / 2]; uint32_t co[(K + 1) / 2]; };
+
+template <int K>
+__device__ __forceinline__ uint32_t tap_y(const Taps<K>& t, int i)        // ky[i], 0 <= i < K
+{
+    return (i & 1) ? t.ce[i >> 1] >> 16 : t.ce[i >> 1] & 0xffffu;
+}
 
 template <int C, int K>
 __device__ __forceinline__ void hpass(us2 (&h)[8], const Win<C, K / 2>& W, const Taps<K>& t)
@@ -263,11 +274,32 @@ __device__ __forceinline__ void hpass(us2 (&h)[8], const Win<C, K / 2>& W, const
     }
 }
 
+// row results of two consecutive rows -> per-column pairs: pl[s] = (a[s].lo, b[s].lo), ph[s] = (a[s].hi, b[s].hi)
+template <int C, int K>
+__device__ __forceinline__ void make_pair(uint32_t (&pl)[8], uint32_t (&ph)[8], const Win<C, K / 2>& wa,
+                                          const Win<C, K / 2>& wb, const Taps<K>& t)
+{
+    us2 ha[8], hb[8];
+    hpass<C, K>(ha, wa, t);
+    hpass<C, K>(hb, wb, t);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const uint32_t a = __builtin_bit_cast(uint32_t, ha[s]), b = __builtin_bit_cast(uint32_t, hb[s]);
+        pl[s] = __builtin_amdgcn_perm(b, a, 0x05040100u);
+        ph[s] = __builtin_amdgcn_perm(b, a, 0x07060302u);
+    }
+}
+
+__device__ __forceinline__ uint32_t dot2(uint32_t pair, uint32_t taps, uint32_t acc)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, pair), __builtin_bit_cast(us2, taps), acc, false);
+}
+
 template <int C, int K>
 __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_small_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                              ConvGeom g, Taps<K> t)
 {
-    constexpr int R = K / 2;
+    constexpr int R = K / 2, NP = (K + 1) / 2;
     if (blockIdx.x >= g.main_blocks) {                       // ---- border bytes, one per thread
         unsigned img; int y, b;
         if (!border_item(g, blockIdx.x - g.main_blocks, img, y, b)) return;
@@ -283,7 +315,7 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
             uint32_t hsum = 0;
 #pragma unroll
             for (int j = 0; j < K; ++j) hsum += t.kx[j] * rp[xo[j]];
-            acc += t.ky[i] * hsum;
+            acc += tap_y<K>(t, i) * hsum;
         }
         dst[(int64_t)img * g.d_img + (int64_t)y * g.d_row + b] = (uint8_t)(acc >> 16);
         return;
@@ -298,56 +330,53 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
     typedef Win<C, R> WR;
 
     const int nrows = y1 - y0;
-    constexpr int dir = 1;
     const int ys = y0;
     const int tlast = nrows - 1 + 2 * R;                     // last source row of the walk anybody needs
-    auto row = [&](int tt) { return row_ptr(g, simg, ys + dir * ((tt <= tlast ? tt : tlast) - R), R); };
+    auto row = [&](int tt) { return row_ptr(g, simg, ys + ((tt <= tlast ? tt : tlast) - R), R); };   // walk row tt
 
-    us2 hw[K][8];                                            // ring of K row-pass results (statically indexed)
+    uint32_t pl[NP][8], ph[NP][8];                           // ring of NP row pairs (statically indexed)
 #pragma unroll
-    for (int s = 0; s < K - 1; ++s) {                        // prologue: walk rows 0 .. K-2
-        WR W;
-        load_win<C, R>(W, row(s), b0);
-        hpass<C, K>(hw[s], W, t);
+    for (int p = 0; p < NP - 1; ++p) {                       // prologue: pairs 0 .. NP-2
+        WR wa, wb;
+        load_win<C, R>(wa, row(2 * p), b0);
+        load_win<C, R>(wb, row(2 * p + 1), b0);
+        make_pair<C, K>(pl[p], ph[p], wa, wb, t);
     }
-    WR nx[K];
+    constexpr int DP = K == 7 ? 2 : NP;                      // loads run DP pairs ahead (DP divides NP: static slots)
+    WR nx[2 * DP];
 #pragma unroll
-    for (int s = 0; s < K; ++s) load_win<C, R>(nx[s], row(K - 1 + s), b0);
-    for (int i0 = 0; i0 < nrows; i0 += K) {
+    for (int s = 0; s < 2 * DP; ++s) load_win<C, R>(nx[s], row(2 * (NP - 1) + s), b0);
+    for (int j0 = 0; 2 * j0 < nrows; j0 += NP) {
 #pragma unroll
-        for (int s = 0; s < K; ++s) {
-#if IPX_ABLATE & 2          // dev ablation: almost no arithmetic
+        for (int s = 0; s < NP; ++s) {
+            make_pair<C, K>(pl[(s + NP - 1) % NP], ph[(s + NP - 1) % NP], nx[2 * (s % DP)], nx[2 * (s % DP) + 1], t);
+            const int tn = 2 * (j0 + s + NP - 1 + DP);        // refill the two slots just consumed
+            load_win<C, R>(nx[2 * (s % DP)], row(tn), b0);
+            load_win<C, R>(nx[2 * (s % DP) + 1], row(tn + 1), b0);
+            const int y = 2 * (j0 + s);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) hw[(K - 1 + s) % K][q] = __builtin_bit_cast(us2, nx[s].w[(q & 3) + Win<C, R>::HD]);
-#else
-            hpass<C, K>(hw[(K - 1 + s) % K], nx[s], t);
-#endif
-            load_win<C, R>(nx[s], row(i0 + 2 * K - 1 + s), b0);   // refill the slot just consumed
-            if (i0 + s < nrows) {
-                u32x4 o;
-#if IPX_ABLATE & 2
+            for (int odd = 0; odd < 2; ++odd) {
+                if (y + odd < nrows) {
+                    u32x4 o;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = __builtin_bit_cast(uint32_t, hw[s % K][k]) ^ __builtin_bit_cast(uint32_t, hw[(s + K - 1) % K][k + 4]);
-#else
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t lo[2], hi[2];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    uint32_t lo[2], hi[2];
+                        for (int par = 0; par < 2; ++par) {
+                            uint32_t al = 32768u, ah = 32768u;
 #pragma unroll
-                    for (int par = 0; par < 2; ++par) {
-                        uint32_t al = 32768u, ah = 32768u;
-#pragma unroll
-                        for (int i = 0; i < K; ++i) {
-                            const uint32_t hv = __builtin_bit_cast(uint32_t, hw[(s + i) % K][2 * k + par]);
-                            al = mad_lo16(hv, t.ky[i], al);
-                            ah = mad_hi16(hv, t.ky[i], ah);
+                            for (int tt = 0; tt < NP; ++tt) {
+                                const uint32_t c = odd ? t.co[tt] : t.ce[tt];
+                                al = dot2(pl[(s + tt) % NP][2 * k + par], c, al);
+                                ah = dot2(ph[(s + tt) % NP][2 * k + par], c, ah);
+                            }
+                            lo[par] = al;                     // taps sum to 256 -> (acc >> 16) <= 255
+                            hi[par] = ah;
                         }
-                        lo[par] = al;                         // taps sum to 256 -> (acc >> 16) <= 255
-                        hi[par] = ah;
+                        o[k] = pack_acc(lo[0], lo[1], hi[0], hi[1]);
                     }
-                    o[k] = pack_acc(lo[0], lo[1], hi[0], hi[1]);
+                    st16_nt(dimg + (int64_t)(ys + y + odd) * g.d_row + b0, o);
                 }
-#endif
-                st16_nt(dimg + (int64_t)(ys + dir * (i0 + s)) * g.d_row + b0, o);
             }
         }
     }
@@ -403,7 +432,7 @@ int env_int(const char* name, int dflt)
 }
 
 // hd4 = 4 * ceil(r*c/4): halo bytes a main-region lane reads on either side (<= 16)
-int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c, int r, int max_wpb,
+int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c, int r, int max_wpb, int gran,
                    int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
                    const uint8_t* top, const uint8_t* bot)
 {
@@ -430,6 +459,16 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
         const int lo = r <= 1 ? 16 : r == 2 ? 24 : 48, hi = 128;      // measured optima on 16 x 4K (scripts/opbench.py)
         if (seg < lo) seg = lo;
         if (seg > hi) seg = hi;
+        seg = (seg + gran / 2) / gran * gran;                 // whole loop iterations (rows per unrolled walk step)
+        // between one and two rounds of resident waves (256 CUs x 4 SIMDs x ~4 waves) the second round is a long
+        // tail: stretch the segments so that everything is resident at once (gray 4K batches: 55 -> 51 us)
+        const int64_t slots = 4096, strips = (int64_t)n * (g.nstrips ? g.nstrips : 1);
+        const int64_t waves = strips * ((h + seg - 1) / seg);
+        if (waves > slots && waves < 2 * slots) {
+            int s2 = (int)((strips * h + slots - 1) / slots);
+            s2 = (s2 + gran - 1) / gran * gran;
+            if (s2 > seg && s2 <= hi) seg = s2;
+        }
     }
     if (seg > h) seg = h;
     g.seg_rows = seg;
@@ -457,7 +496,7 @@ int launch_conv3(const char* fn, void* stream, const uint8_t* src, uint8_t* dst,
                  int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* top, const uint8_t* bot)
 {
     ConvGeom g;
-    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, 1, kMaxWavesPerBlock, s_row, s_img, d_row, d_img, top, bot)) return rc;
+    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, 1, kMaxWavesPerBlock, 4, s_row, s_img, d_row, d_img, top, bot)) return rc;
     const dim3 grid(conv_grid(g)), block(conv_block(g));
     hipStream_t st = (hipStream_t)stream;
     switch (c) {
@@ -475,7 +514,12 @@ void launch_sep_small(hipStream_t st, const uint8_t* src, uint8_t* dst, const Co
                       const uint16_t* kx, const uint16_t* ky)
 {
     Taps<K> t;
-    for (int i = 0; i < K; ++i) { t.kx[i] = kx[i]; t.ky[i] = ky[i]; }
+    for (int i = 0; i < K; ++i) t.kx[i] = kx[i];
+    for (int p = 0; p < (K + 1) / 2; ++p) {
+        const uint32_t a = ky[2 * p], b = 2 * p + 1 < K ? ky[2 * p + 1] : 0u, z = 2 * p >= 1 ? ky[2 * p - 1] : 0u;
+        t.ce[p] = a | (b << 16);                              // rows (2p, 2p+1) of an even output row's window
+        t.co[p] = z | (a << 16);                              // ... of an odd output row's window (shifted by one)
+    }
     hipLaunchKernelGGL((sep_small_kernel<C, K>), dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g, t);
 }
 
@@ -527,7 +571,7 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     if (!kx_q8 || !ky_q8) return ipx_fail(IPX_ERR_INVALID, "%s: null taps", fn);
     if (k < 1 || (k & 1) == 0 || k > IPX_MAX_GAUSS_K) return ipx_fail(IPX_ERR_INVALID, "%s: k=%d must be odd and in 1..%d", fn, k, IPX_MAX_GAUSS_K);
     ConvGeom g;
-    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, k / 2, k <= 5 ? kMaxWavesPerBlock : 8, s_row, s_img, d_row, d_img, top_halo, bottom_halo)) return rc;
+    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, k / 2, k <= 5 ? kMaxWavesPerBlock : 8, k <= 7 ? k + 1 : 1, s_row, s_img, d_row, d_img, top_halo, bottom_halo)) return rc;
     unsigned sx = 0, sy = 0;
     for (int i = 0; i < k; ++i) {
         if (kx_q8[i] > 256 || ky_q8[i] > 256) return ipx_fail(IPX_ERR_INVALID, "%s: tap %d exceeds 256 (Q0.8 of 1.0)", fn, i);
