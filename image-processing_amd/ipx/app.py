@@ -20,8 +20,8 @@ from flask import Flask, jsonify, request
 
 from . import codec, luts
 
-OUT_OF_SCOPE = ("pca_nn", "count_objects", "frequency_filter", "wiener", "median")
-DENOISE_OUT_OF_SCOPE = ("median", "bilateral", "nlm")    # cv2 rank / edge-preserving / patch filters
+OUT_OF_SCOPE = ("pca_nn", "count_objects", "frequency_filter", "wiener")
+DENOISE_OUT_OF_SCOPE = ("bilateral", "nlm")              # cv2 edge-preserving / patch filters
 
 
 class GpuBackend:
@@ -106,13 +106,17 @@ def create_app(backend=None) -> Flask:
             if kernel % 2 == 0:
                 kernel += 1
             kernel = max(3, min(31, kernel))
-            if method_name != "lee":                                 # every other branch is a cv2 filter (C10)
+            if method_name not in ("lee", "median"):                 # bilateral / NLM / the default branch: cv2 filters (C10)
                 return {"error": f"denoise_manual method '{method_name}' is outside the GPU hot path of this "
-                                         "backend (only method=lee is built: SURVEY.md section 8(f))"}, 501
-            # histogram analysis (server.py:190-211) from the GPU's exact 256-bin histogram, Lee filter on the GPU
-            hist, img_denoised = b.run(lambda ops, t: (ops.hist(t), ops.lee_filter(t, kernel)), img)
+                                         "backend (methods lee and median are built: SURVEY.md section 8(f))"}, 501
+            # histogram analysis (server.py:190-211) from the GPU's exact 256-bin histogram, filter on the GPU
+            if method_name == "lee":
+                hist, img_denoised = b.run(lambda ops, t: (ops.hist(t), ops.lee_filter(t, kernel)), img)
+                method = f"Lee Filter (w={kernel})"
+            else:
+                hist, img_denoised = b.run(lambda ops, t: (ops.hist(t), ops.median_blur(t, kernel)), img)
+                method = f"Median (k={kernel})"
             st = b.stats_from_hist(hist, method_name)
-            method = f"Lee Filter (w={kernel})"
             params = {"method": method, "kernel": kernel,
                       "histogram": {"extreme_ratio": round(st["extreme_ratio"], 4), "variance": round(st["variance"], 2),
                                     "cv": round(st["cv"], 4), "suggested_method": st["suggested_method"]}}
@@ -146,6 +150,46 @@ def create_app(backend=None) -> Flask:
                 method = "No sharpening"
             params = {"method": method, "color": is_color}
             return {"dataURL": codec.to_data_url_png(img_sharp), "message": f"Sharpened: {method}", "params": params}, 200
+
+        if mode == "median":                                        # server.py:390-441 (NLM step: out of scope)
+            def _int(name, dflt):
+                try:
+                    return int(form.get(name, dflt))
+                except Exception:
+                    return int(dflt)
+            k = _int("k", "3")
+            if k % 2 == 0:
+                k += 1
+            k = max(3, min(31, k))
+            g = _int("gauss", "0")
+            if g % 2 == 0 and g > 0:
+                g += 1
+            if g < 1:
+                g = 0
+            morph = _int("morph", "0")
+            if morph % 2 == 0 and morph > 0:
+                morph += 1
+            if morph < 1:
+                morph = 0
+            passes = max(1, min(4, _int("passes", "1")))
+            if form.get("nlm", "0") == "1":
+                return {"error": "mode 'median' with nlm=1 (cv2.fastNlMeansDenoising) is outside the GPU hot path of this backend"}, 501
+            if morph > 31 or g > 255:
+                return {"error": "mode 'median': morph > 31 or gauss > 255 is not supported by this backend"}, 501
+            img = ensure_gray_uint8(b, data)
+
+            def pipeline(ops, t):
+                if g > 0:
+                    t = ops.gaussian_blur(t, g)
+                for _ in range(passes):
+                    t = ops.median_blur(t, k)
+                if morph > 0:
+                    se = ops.ellipse_se(morph)
+                    t = ops.morph_close(ops.morph_open(t, se), se)
+                return t
+            out = b.run(pipeline, img)
+            params = {"median_k": int(k), "pre_gauss": int(g), "morph_k": int(morph), "passes": int(passes)}
+            return {"dataURL": codec.to_data_url_png(out), "message": "ok", "params": params}, 200
 
         if mode == "pca":                                           # server.py:353-356
             return {"error": "mode 'pca' has been removed on server. Use 'pca_nn' for PCA+NN inference "

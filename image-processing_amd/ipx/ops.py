@@ -322,3 +322,44 @@ def stats_from_hist(h: np.ndarray, method_name: str = "median") -> dict:
         suggested = method_name
     return {"extreme_ratio": extreme_ratio, "mean": mean_val, "variance": var, "cv": cv_val,
             "suggested_method": suggested}
+
+
+# ---- median and morphology of the `median` pipeline -----------------
+def median_blur(src: torch.Tensor, k: int) -> torch.Tensor:
+    """cv2.medianBlur(img, k) on gray uint8 (server.py:215, 430): BORDER_REPLICATE, exact median."""
+    s = _gray(src)
+    with torch.cuda.device(s.t.device):
+        out = s.like()
+        _lib.call("ipx_median_blur_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w, s.row, s.img, s.w, s.w * s.h, int(k))
+    return s.restore(out)
+
+
+def ellipse_se(m: int) -> np.ndarray:
+    """cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (m, m)) (server.py:432), OpenCV's row-extent formula."""
+    r = c = m // 2
+    inv_r2 = 1.0 / (r * r) if r else 0.0
+    se = np.zeros((m, m), np.uint8)
+    for i in range(m):
+        dy = i - r
+        if abs(dy) <= r:
+            dx = int(np.rint(c * np.sqrt((r * r - dy * dy) * inv_r2)))       # saturate_cast<int> = round half to even
+            se[i, max(c - dx, 0):min(c + dx + 1, m)] = 1
+    return se
+
+
+def _morph(src: torch.Tensor, se, op: int) -> torch.Tensor:
+    s = _gray(src)
+    se = np.ascontiguousarray(se, np.uint8)
+    if se.ndim != 2:
+        raise ValueError("structuring element must be 2-D")
+    with torch.cuda.device(s.t.device):
+        out = s.like()
+        _lib.call("ipx_morph_u8", _stream(), s.ptr, out.data_ptr(), s.n, s.h, s.w, s.row, s.img, s.w, s.w * s.h,
+                  op, se.ctypes.data, se.shape[0], se.shape[1])
+    return s.restore(out)
+
+
+def erode(src, se): return _morph(src, se, 0)
+def dilate(src, se): return _morph(src, se, 1)
+def morph_open(src, se): return dilate(erode(src, se), se)      # cv2.morphologyEx(MORPH_OPEN), server.py:433
+def morph_close(src, se): return erode(dilate(src, se), se)     # cv2.morphologyEx(MORPH_CLOSE), server.py:434

@@ -178,6 +178,23 @@ int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int
                       int64_t src_row_stride, int64_t src_img_stride,
                       int64_t dst_row_stride, int64_t dst_img_stride, int window_size);
 
+/* ---- rank / morphological filters ------------------------- */
+
+/* cv2.medianBlur(img, k) -- server.py:215 (denoise_manual, method=median) and :430 (mode=median).
+ * Gray uint8, odd k in 1..31, BORDER_REPLICATE; the exact median of the k x k window.  src != dst. */
+int ipx_median_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                       int64_t src_row_stride, int64_t src_img_stride,
+                       int64_t dst_row_stride, int64_t dst_img_stride, int k);
+
+/* cv2.erode (op = 0) / cv2.dilate (op = 1) with a structuring element -- the two halves of
+ * cv2.morphologyEx(img, MORPH_OPEN / MORPH_CLOSE, se), server.py:433-434.  se_host: HOST array of
+ * se_rows x se_cols bytes (non-zero = member), odd sides in 1..31, anchor at the centre; pixels
+ * outside the image do not take part (OpenCV's default morphology border).  src != dst. */
+int ipx_morph_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                 int64_t src_row_stride, int64_t src_img_stride,
+                 int64_t dst_row_stride, int64_t dst_img_stride,
+                 int op, const uint8_t* se_host, int se_rows, int se_cols);
+
 #ifdef __cplusplus
 }
 #endif

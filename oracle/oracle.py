@@ -345,6 +345,63 @@ def denoise_stats(img: np.ndarray, method_name: str = "median") -> dict:
 
 
 # --------------------------------------------------------------------------
+# (f)-4  median / morphology of the `median` pipeline     server.py:215, 426-434
+#        [OCV-MEM] definitions; parity unpinned (OpenCV absent)
+# --------------------------------------------------------------------------
+def median_blur_u8(img: np.ndarray, k: int) -> np.ndarray:
+    """cv2.medianBlur: BORDER_REPLICATE, the (k*k-1)/2-th smallest value of the k x k window."""
+    r = k // 2
+    p = np.pad(img, r, mode="edge")
+    from numpy.lib.stride_tricks import sliding_window_view
+    win = sliding_window_view(p, (k, k)).reshape(img.shape[0], img.shape[1], k * k)
+    return np.partition(win, (k * k - 1) // 2, axis=2)[:, :, (k * k - 1) // 2].astype(np.uint8)
+
+
+def ellipse_se(m: int) -> np.ndarray:
+    """cv2.getStructuringElement(MORPH_ELLIPSE, (m, m)): row i spans [c-dx, c+dx] with
+    dx = cvRound(c*sqrt((r*r-dy*dy)/(r*r)))."""
+    r = c = m // 2
+    se = np.zeros((m, m), np.uint8)
+    for i in range(m):
+        dy = i - r
+        dx = int(np.rint(c * np.sqrt((r * r - dy * dy) * (1.0 / (r * r) if r else 0.0))))
+        se[i, max(c - dx, 0):min(c + dx + 1, m)] = 1
+    return se
+
+
+def _morph(img: np.ndarray, se: np.ndarray, dilate: bool) -> np.ndarray:
+    kh, kw = se.shape
+    ry, rx = kh // 2, kw // 2
+    fill = 0 if dilate else 255                     # out-of-image pixels never win
+    p = np.pad(img, ((ry, ry), (rx, rx)), mode="constant", constant_values=fill)
+    out = np.full(img.shape, fill, np.uint8)
+    for i in range(kh):
+        for j in range(kw):
+            if se[i, j]:
+                v = p[i:i + img.shape[0], j:j + img.shape[1]]
+                out = np.maximum(out, v) if dilate else np.minimum(out, v)
+    return out
+
+
+def erode_u8(img, se): return _morph(img, np.asarray(se, np.uint8), False)
+def dilate_u8(img, se): return _morph(img, np.asarray(se, np.uint8), True)
+def morph_open_u8(img, se): return dilate_u8(erode_u8(img, se), se)
+def morph_close_u8(img, se): return erode_u8(dilate_u8(img, se), se)
+
+
+def median_pipeline_u8(img: np.ndarray, k: int, g: int, morph: int, passes: int) -> np.ndarray:
+    """server.py:426-434 (without the optional NLM step)."""
+    if g > 0:
+        img = gaussian_blur_u8(img, g)
+    for _ in range(passes):
+        img = median_blur_u8(img, k)
+    if morph > 0:
+        se = ellipse_se(morph)
+        img = morph_close_u8(morph_open_u8(img, se), se)
+    return img
+
+
+# --------------------------------------------------------------------------
 # pipelines BASELINE.json names (used by tests and bench cpu_baseline)
 # --------------------------------------------------------------------------
 def pipeline_cfg1(bgr: np.ndarray) -> np.ndarray:

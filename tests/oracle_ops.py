@@ -62,6 +62,14 @@ class OracleOps:
 
     @staticmethod
     def lee_filter(t, window_size=5): return _t(O.lee_filter_u8(_np(t), window_size))
+    @staticmethod
+    def median_blur(t, k): return _t(O.median_blur_u8(_np(t), k))
+    @staticmethod
+    def ellipse_se(m): return O.ellipse_se(m)
+    @staticmethod
+    def morph_open(t, se): return _t(O.morph_open_u8(_np(t), se))
+    @staticmethod
+    def morph_close(t, se): return _t(O.morph_close_u8(_np(t), se))
 
 
 class OracleBackend:

@@ -21,6 +21,7 @@ def test_opencv_backed_modes_on_gpu_backend(dev):
     T.test_opencv_backed_modes_contract(client)
     T.test_extension_modes(client)
     T.test_batch_endpoint(client)
+    T.test_median_modes_contract(client)
 
 
 def test_batch_sharder_two_workers_one_gpu(dev):

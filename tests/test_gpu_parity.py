@@ -302,6 +302,49 @@ def test_lee_filter_golden_and_batch(dev, golden):
     np.testing.assert_array_equal(host(ops.lee_filter(dev_t(extremes, dev), 7)), O.lee_filter_u8(extremes, 7))
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (2, 3), (5, 40), (33, 70), (64, 97), (130, 96)])
+@pytest.mark.parametrize("k", [1, 3, 5, 7, 11, 31])
+def test_median_blur(dev, shape, k):
+    """cv2.medianBlur restated (BORDER_REPLICATE, exact median), incl. images smaller than the window."""
+    rng = np.random.default_rng(shape[1] * 7 + k)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    if shape[0] > 8:
+        img[rng.random(shape) < 0.1] = 255
+        img[2:6, 3:9] = 17
+    np.testing.assert_array_equal(host(ops.median_blur(dev_t(img, dev), k)), O.median_blur_u8(img, k))
+
+
+def test_median_extremes_and_batch(dev):
+    rng = np.random.default_rng(2)
+    for img in (np.zeros((20, 30), np.uint8), np.full((20, 30), 255, np.uint8),
+                np.where(rng.random((40, 50)) < 0.5, 0, 255).astype(np.uint8)):
+        for k in (3, 9):
+            np.testing.assert_array_equal(host(ops.median_blur(dev_t(img, dev), k)), O.median_blur_u8(img, k))
+    batch = rng.integers(0, 256, (3, 37, 45, 1), dtype=np.uint8)
+    got = host(ops.median_blur(dev_t(batch, dev), 5))
+    for i in range(3):
+        np.testing.assert_array_equal(got[i, :, :, 0], O.median_blur_u8(batch[i, :, :, 0], 5))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (4, 9), (33, 70), (64, 97)])
+@pytest.mark.parametrize("m", [1, 3, 5, 7, 15, 31])
+def test_morphology(dev, shape, m):
+    """cv2.erode / dilate / morphologyEx(OPEN, CLOSE) restated with OpenCV's elliptical structuring element."""
+    rng = np.random.default_rng(shape[1] + m)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    se = ops.ellipse_se(m)
+    np.testing.assert_array_equal(se, O.ellipse_se(m))
+    t = dev_t(img, dev)
+    np.testing.assert_array_equal(host(ops.erode(t, se)), O.erode_u8(img, se))
+    np.testing.assert_array_equal(host(ops.dilate(t, se)), O.dilate_u8(img, se))
+    np.testing.assert_array_equal(host(ops.morph_open(t, se)), O.morph_open_u8(img, se))
+    np.testing.assert_array_equal(host(ops.morph_close(t, se)), O.morph_close_u8(img, se))
+    rect = np.ones((3, 5), np.uint8)                                  # non-square, asymmetric support
+    rect[0, 0] = 0
+    np.testing.assert_array_equal(host(ops.erode(t, rect)), O.erode_u8(img, rect))
+    np.testing.assert_array_equal(host(ops.dilate(t, rect)), O.dilate_u8(img, rect))
+
+
 def test_denoise_stats_on_device(dev):
     """server.py:190-211 from the device histogram: flags equal, moments equal to float32 rounding (the reference
     reduces float32 pixels with numpy; the product uses exact counts in float64)."""

@@ -112,11 +112,36 @@ def test_out_of_scope_modes_say_so(client):
     for method in app_mod.DENOISE_OUT_OF_SCOPE + ("whatever",):
         st, js = post(client, gray, "denoise_manual", method=method)
         assert st == 501 and "outside the GPU hot path" in js["error"]
-    st, js = post(client, gray, "denoise_manual")                    # default method is median (server.py:184)
+    st, js = post(client, gray, "median", nlm=1)
     assert st == 501
     r = client.post("/api/process", data={"mode": "gray8", "file": (io.BytesIO(b"not an image"), "x.png")},
                     content_type="multipart/form-data")
     assert r.status_code == 500 and "Cannot decode image" in r.get_json()["error"]
+
+
+def test_median_modes_contract(client):
+    """mode=median (server.py:390-441) and denoise_manual's default method (server.py:184, 214-216): parameter
+    parsing / clamps / params / messages as the reference; pixels against the oracle restatement (OpenCV unpinned)."""
+    rng = np.random.default_rng(8)
+    gray = rng.integers(0, 256, (40, 52), dtype=np.uint8)
+    gray[rng.random(gray.shape) < 0.05] = 255
+    st, js = post(client, gray, "median")                            # defaults: k=3, no gauss, no morph, 1 pass
+    assert st == 200 and js["message"] == "ok" and js["params"] == {"median_k": 3, "pre_gauss": 0, "morph_k": 0, "passes": 1}
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.median_blur_u8(gray, 3))
+    st, js = post(client, gray, "median", k=4, gauss=2, morph=2, passes=9)      # even -> +1, passes clamp 4
+    assert js["params"] == {"median_k": 5, "pre_gauss": 3, "morph_k": 3, "passes": 4}
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.median_pipeline_u8(gray, 5, 3, 3, 4))
+    st, js = post(client, gray, "median", k="x", gauss=-3, morph=5, passes=0)   # bad int -> default; negatives -> 0
+    assert js["params"] == {"median_k": 3, "pre_gauss": 0, "morph_k": 5, "passes": 1}
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.median_pipeline_u8(gray, 3, 0, 5, 1))
+    st, js = post(client, gray, "median", k=99)
+    assert js["params"]["median_k"] == 31
+    st, js = post(client, gray, "denoise_manual")                    # default method is median, kernel 5
+    assert st == 200 and js["message"] == "Manual denoise: Median (k=5)" and js["params"]["method"] == "Median (k=5)"
+    assert js["params"]["kernel"] == 5 and set(js["params"]["histogram"]) == {"extreme_ratio", "variance", "cv", "suggested_method"}
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.median_blur_u8(gray, 5))
+    st, js = post(client, gray, "denoise_manual", method="median", kernel=2)    # even -> 3
+    np.testing.assert_array_equal(codec.from_data_url_png(js["dataURL"]), O.median_blur_u8(gray, 3))
 
 
 def test_batch_endpoint(client):

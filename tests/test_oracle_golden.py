@@ -177,3 +177,22 @@ def test_denoise_stats_thresholds():
     sp = np.full((64, 64), 128, np.uint8)
     sp[::4, ::4] = 0
     assert O.denoise_stats(sp)["suggested_method"] == "median"
+
+
+def test_median_and_morphology_anchors():
+    """Known answers that need no OpenCV: OpenCV's documented 3x3 / 5x5 elliptical elements, median of constant and of
+    a salt-and-pepper speck, opening removes an isolated bright pixel, closing an isolated dark one."""
+    assert O.ellipse_se(1).tolist() == [[1]]
+    assert O.ellipse_se(3).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
+    assert O.ellipse_se(5).tolist() == [[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]]
+    img = np.full((9, 9), 100, np.uint8)
+    assert np.array_equal(O.median_blur_u8(img, 5), img)
+    img[4, 4] = 255
+    assert np.array_equal(O.median_blur_u8(img, 3), np.full((9, 9), 100, np.uint8))
+    se = O.ellipse_se(3)
+    assert np.array_equal(O.morph_open_u8(img, se), np.full((9, 9), 100, np.uint8))
+    img[4, 4] = 0
+    assert np.array_equal(O.morph_close_u8(img, se), np.full((9, 9), 100, np.uint8))
+    ramp = np.arange(81, dtype=np.uint8).reshape(9, 9)
+    assert O.median_blur_u8(ramp, 3)[0, 0] == np.sort([0, 0, 1, 0, 0, 1, 9, 9, 10])[4]      # BORDER_REPLICATE corner
+    assert O.erode_u8(ramp, np.ones((3, 3), np.uint8))[0, 0] == 0 and O.dilate_u8(ramp, np.ones((3, 3), np.uint8))[8, 8] == 80
