@@ -44,9 +44,6 @@ class GpuBackend:
             s = self._tls.stream = self.torch.cuda.Stream(device=self.device)
         return s
 
-    def stats_from_hist(self, hist, method_name):
-        return self.ops.stats_from_hist(hist, method_name)
-
     def run(self, fn, *arrays):
         """Stage arrays to the device, run fn(ops, *tensors) on this thread's stream, bring results back."""
         torch = self.torch
@@ -109,14 +106,13 @@ def create_app(backend=None) -> Flask:
             if method_name not in ("lee", "median"):                 # bilateral / NLM / the default branch: cv2 filters (C10)
                 return {"error": f"denoise_manual method '{method_name}' is outside the GPU hot path of this "
                                          "backend (methods lee and median are built: SURVEY.md section 8(f))"}, 501
-            # histogram analysis (server.py:190-211) from the GPU's exact 256-bin histogram, filter on the GPU
+            # histogram analysis (server.py:190-211) and the filter, both on the GPU
             if method_name == "lee":
-                hist, img_denoised = b.run(lambda ops, t: (ops.hist(t), ops.lee_filter(t, kernel)), img)
+                st, img_denoised = b.run(lambda ops, t: (ops.denoise_stats(t, method_name), ops.lee_filter(t, kernel)), img)
                 method = f"Lee Filter (w={kernel})"
             else:
-                hist, img_denoised = b.run(lambda ops, t: (ops.hist(t), ops.median_blur(t, kernel)), img)
+                st, img_denoised = b.run(lambda ops, t: (ops.denoise_stats(t, method_name), ops.median_blur(t, kernel)), img)
                 method = f"Median (k={kernel})"
-            st = b.stats_from_hist(hist, method_name)
             params = {"method": method, "kernel": kernel,
                       "histogram": {"extreme_ratio": round(st["extreme_ratio"], 4), "variance": round(st["variance"], 2),
                                     "cv": round(st["cv"], 4), "suggested_method": st["suggested_method"]}}

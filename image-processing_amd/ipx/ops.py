@@ -291,20 +291,52 @@ def lee_filter(src: torch.Tensor, window_size: int = 5) -> torch.Tensor:
     return s.restore(out)
 
 
+def pairwise_sum_lut(src: torch.Tensor, table) -> np.float32:
+    """np.add.reduce(table[img.flatten()].astype(np.float32)) in numpy's own order of float32 additions (blocking)."""
+    s = _gray(src)
+    t = s.t if (s.row == s.w and (s.n == 1 or s.img == s.w * s.h)) else s.t.contiguous()
+    tab = np.ascontiguousarray(table, np.float32)
+    if tab.shape != (256,):
+        raise ValueError("table must have 256 float32 entries")
+    res = np.zeros(1, np.float32)
+    with torch.cuda.device(t.device):
+        _lib.call("ipx_pairwise_sum_lut_f32", _stream(), t.data_ptr(), int(t.numel()), tab.ctypes.data, res.ctypes.data)
+    return res[0]
+
+
 def denoise_stats(src: torch.Tensor, method_name: str = "median") -> dict:
-    """The histogram analysis of mode=denoise_manual (server.py:190-211) for ONE gray image, from the exact 256-bin
-    histogram of the GPU: extreme_ratio = (count(0) + count(255)) / total, mean, variance, cv = std / mean and the
-    suggested method.  The reference reduces the float32 pixel array with numpy (pairwise float32 sums, relative error
-    ~1e-6 on megapixel images); here the moments come from integer counts in float64, so the values agree with the
-    reference's to float32 rounding, not bit for bit (tolerance stated in tests/test_gpu_parity.py)."""
+    """The histogram analysis of mode=denoise_manual (server.py:190-211) for ONE gray image, bit-identical to the
+    reference: counts of 0 / 255 from the GPU histogram; np.mean / np.var / np.std of the float32 pixel array are
+    float32 sums in numpy's fixed order, formed on the GPU (ipx_pairwise_sum_lut_f32); the scalar steps around them are
+    the reference's own numpy expressions on float32 scalars / 256-level tables."""
     if src.ndim != 2:
         raise ValueError("denoise_stats: one H x W gray image expected")
     h = hist(src).to("cpu").numpy().astype(np.int64)
-    return stats_from_hist(h, method_name)
+    n = int(src.numel())
+    total = float(n)
+    extreme_ratio = float((int(h[0]) + int(h[255])) / total)                       # server.py:193-195
+    lv = np.arange(256, dtype=np.uint8).astype(np.float32)
+    mean32 = np.float32(pairwise_sum_lut(src, lv) / n)                             # np.mean(flat): sum / count in float32
+    mean_val = float(mean32)
+    dev = lv - mean32                                                              # np.var: x = arr - arrmean; x = x * x
+    var32 = np.float32(pairwise_sum_lut(src, dev * dev) / n)
+    var = float(var32)
+    cv_val = float(np.sqrt(var32) / (mean_val + 1e-12))                            # np.std(flat) / (mean_val + 1e-12)
+    if extreme_ratio > 0.02:
+        suggested = "median"
+    elif cv_val > 0.28:
+        suggested = "lee"
+    elif 100 < var < 2000:
+        suggested = "bilateral"
+    else:
+        suggested = method_name
+    return {"extreme_ratio": extreme_ratio, "mean": mean_val, "variance": var, "cv": cv_val,
+            "suggested_method": suggested}
 
 
 def stats_from_hist(h: np.ndarray, method_name: str = "median") -> dict:
-    """server.py:190-211 from a 256-bin histogram (host arithmetic, float64)."""
+    """server.py:190-211 from a 256-bin histogram alone (float64 on exact counts): what a row-partitioned image can
+    compute after its histogram all-reduce.  Agrees with denoise_stats to float32 rounding, not bit for bit."""
     h = np.asarray(h, np.int64)
     total = float(h.sum())
     extreme_ratio = float((int(h[0]) + int(h[255])) / total)

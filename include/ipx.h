@@ -178,6 +178,15 @@ int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int
                       int64_t src_row_stride, int64_t src_img_stride,
                       int64_t dst_row_stride, int64_t dst_img_stride, int window_size);
 
+/* np.add.reduce(table[src].astype(np.float32)) over a CONTIGUOUS uint8 array of `count` elements
+ * on the device, bit for bit: numpy's float32 reduction order (8192-element buffers added in
+ * sequence, pairwise summation inside each).  With table = the levels it is the sum behind
+ * np.mean(flat), with table = fl(fl(v - mean)^2) the one behind np.var / np.std of
+ * mode=denoise_manual -- server.py:197-200.  table_host: 256 floats (host).  BLOCKING: synchronises
+ * `stream` and writes the float32 sum to *result_host. */
+int ipx_pairwise_sum_lut_f32(void* stream, const uint8_t* src, int64_t count,
+                             const float* table_host, float* result_host);
+
 /* ---- rank / morphological filters ------------------------- */
 
 /* cv2.medianBlur(img, k) -- server.py:215 (denoise_manual, method=median) and :430 (mode=median).

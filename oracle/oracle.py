@@ -344,6 +344,44 @@ def denoise_stats(img: np.ndarray, method_name: str = "median") -> dict:
             "suggested_method": s}
 
 
+def pairwise_sum_f32(a: np.ndarray) -> np.float32:
+    """What np.add.reduce does to a contiguous float32 vector, spelled out (numpy 2.2, default bufsize): buffers of
+    8192 elements are summed PAIRWISE (blocks of <= 128 values with 8 interleaved accumulators, larger inputs halved at
+    n/2 rounded down to a multiple of 8) and added to the running total in sequence.  The GPU statistics kernel
+    (ipx_stats.hip) follows this order; tests compare this function with np.add.reduce itself."""
+    a = np.ascontiguousarray(a, np.float32)
+
+    def block(v):
+        n = len(v)
+        if n < 8:
+            res = np.float32(0)
+            for x in v:
+                res = np.float32(res + x)
+            return res
+        r = v[:8].copy()
+        m = n - n % 8
+        for i in range(8, m, 8):
+            r = r + v[i:i + 8]
+        res = np.float32(np.float32(np.float32(r[0] + r[1]) + np.float32(r[2] + r[3])) +
+                         np.float32(np.float32(r[4] + r[5]) + np.float32(r[6] + r[7])))
+        for x in v[m:]:
+            res = np.float32(res + x)
+        return res
+
+    def pw(v):
+        n = len(v)
+        if n <= 128:
+            return block(v)
+        n2 = n // 2
+        n2 -= n2 % 8
+        return np.float32(pw(v[:n2]) + pw(v[n2:]))
+
+    res = np.float32(0)
+    for o in range(0, len(a), 8192):
+        res = np.float32(res + pw(a[o:o + 8192]))
+    return res
+
+
 # --------------------------------------------------------------------------
 # (f)-4  median / morphology of the `median` pipeline     server.py:215, 426-434
 #        [OCV-MEM] definitions; parity unpinned (OpenCV absent)

@@ -63,6 +63,8 @@ class OracleOps:
     @staticmethod
     def lee_filter(t, window_size=5): return _t(O.lee_filter_u8(_np(t), window_size))
     @staticmethod
+    def denoise_stats(t, method_name="median"): return O.denoise_stats(_np(t), method_name)
+    @staticmethod
     def median_blur(t, k): return _t(O.median_blur_u8(_np(t), k))
     @staticmethod
     def ellipse_se(m): return O.ellipse_se(m)
@@ -74,12 +76,8 @@ class OracleOps:
 
 class OracleBackend:
     """app.GpuBackend stand-in: numpy in, numpy out."""
-    def stats_from_hist(self, hist, method_name):
-        import ipx.ops as real_ops                      # pure host arithmetic on 256 counts (no GPU involved)
-        return real_ops.stats_from_hist(hist, method_name)
-
     def run(self, fn, *arrays):
         out = fn(OracleOps, *[_t(a) for a in arrays])
         if isinstance(out, tuple):
-            return [o.numpy() for o in out]
-        return out.numpy()
+            return [o.numpy() if isinstance(o, torch.Tensor) else o for o in out]
+        return out.numpy() if isinstance(out, torch.Tensor) else out

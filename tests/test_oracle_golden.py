@@ -196,3 +196,16 @@ def test_median_and_morphology_anchors():
     ramp = np.arange(81, dtype=np.uint8).reshape(9, 9)
     assert O.median_blur_u8(ramp, 3)[0, 0] == np.sort([0, 0, 1, 0, 0, 1, 9, 9, 10])[4]      # BORDER_REPLICATE corner
     assert O.erode_u8(ramp, np.ones((3, 3), np.uint8))[0, 0] == 0 and O.dilate_u8(ramp, np.ones((3, 3), np.uint8))[8, 8] == 80
+
+
+def test_numpy_reduction_order_is_what_the_stats_kernel_assumes():
+    """ipx_stats.hip reproduces np.add.reduce's float32 order (8192-element buffers, pairwise inside): pin that order
+    against this numpy, on data whose float32 sum depends on it."""
+    rng = np.random.default_rng(21)
+    for n in (1, 7, 9, 128, 129, 961, 8191, 8192, 8193, 20000, 123457, 300 * 411):
+        a = (rng.random(n) * 255).astype(np.float32)
+        assert O.pairwise_sum_f32(a) == np.add.reduce(a), n
+        b = rng.integers(0, 256, n).astype(np.float32)
+        assert O.pairwise_sum_f32(b * b) == np.add.reduce(b * b), n
+    big = rng.integers(0, 256, 1080 * 1920, dtype=np.uint8).astype(np.float32)     # sums beyond 2^24: rounding order matters
+    assert O.pairwise_sum_f32(big) == np.add.reduce(big) == np.float32(np.mean(big) * 0 + np.add.reduce(big))
