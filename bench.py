@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="4K RGB frames per GPU per step")
-    ap.add_argument("--cpu-sample", type=int, default=40, help="passes of the CPU oracle over 4 frames (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=250, help="passes of the CPU oracle over 4 frames, ~15 s of CPU work, capped at 30 s (0 = skip)")
     ap.add_argument("--ops-table", action="store_true", help="also time ops that are not part of the step, back to back")
     args = ap.parse_args()
 
