@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="4K RGB frames per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=250, help="passes of the CPU oracle over 4 frames, ~15 s of CPU work, capped at 30 s (0 = skip)")
+    ap.add_argument("--order", default="gauss_first", choices=["gauss_first", "geq_first", "sobel_mid"], help="order of the three independent ops inside a step")
     ap.add_argument("--ops-table", action="store_true", help="also time ops that are not part of the step, back to back")
     args = ap.parse_args()
 
@@ -76,11 +77,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (one-GPU box): IPX_BENCH_DEVICE pins every rank to one card, IPX_BENCH_BACKEND=gloo replaces RCCL
+    local = int(os.environ.get("IPX_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("IPX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     L.load()
     L.call("ipx_check_device")
 
@@ -94,21 +101,27 @@ def main():
         ("sobel3_gray", "conv3_kernel<SOBEL,1>", 2),
     ]
 
+    ORDERS = {"geq_first": (1, 0, 2), "gauss_first": (0, 1, 2), "sobel_mid": (1, 2, 0)}
+    order = ORDERS[args.order]
+    STEP_OPS = [STEP_OPS[i] for i in order]
+
     def step(ev=None):
         """One pass of the pipeline over the resident batch; `ev` (optional) receives one HIP event per op boundary,
-        recorded on the stream the kernels are launched on (torch's current stream)."""
+        recorded on the stream the kernels are launched on (torch's current stream).  The three ops are independent
+        except that Sobel needs the gray image; --order only changes which runs first."""
+        res = {}
         if ev is not None:
             ev[0].record()
-        g5 = ops.gaussian_blur(bgr, 5)
-        if ev is not None:
-            ev[1].record()
-        gray, eq = ops.bgr2gray_equalize(bgr)      # cvtColor + equalizeHist, histogram taken while gray is written
-        if ev is not None:
-            ev[2].record()
-        sb = ops.sobel(gray)
-        if ev is not None:
-            ev[3].record()
-        return g5, sb, eq
+        for j, i in enumerate(order):
+            if i == 0:
+                res["g5"] = ops.gaussian_blur(bgr, 5)
+            elif i == 1:
+                res["gray"], res["eq"] = ops.bgr2gray_equalize(bgr)   # cvtColor + equalizeHist, histogram taken while gray is written
+            else:
+                res["sb"] = ops.sobel(res["gray"])
+            if ev is not None:
+                ev[j + 1].record()
+        return res["g5"], res["sb"], res["eq"]
 
     def fence():
         torch.cuda.synchronize()
@@ -183,7 +196,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom_name)
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom_name) if tj.get("batch_per_gpu", 16) == B else None    # measured per launch at that batch
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "op": dom_name, "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,

@@ -50,6 +50,6 @@ for k, c in sorted(pmc.items()):
                  (f"{amb:.1f} | {(rd + wr) / amb:.3f} | {amb / us * 1e3:.0f} | {amb / us * 1e3 / 8000:.3f} |" if a else "- | - | - | - |"))
     traffic_json[k] = int((rd + wr) * 1e6)
 open(os.path.join(out, f"{name}_pmc.md"), "w").write("\n".join(lines) + "\n")
-json.dump({"gaussian5_bgr": traffic_json.get("sep_small_kernel<3, 5>"), "per_kernel_bytes": traffic_json,
+json.dump({"gaussian5_bgr": traffic_json.get("sep_small_kernel<3, 5>"), "batch_per_gpu": B, "per_kernel_bytes": traffic_json,
            "source": f"profiles/{name}_pmc.md"}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
