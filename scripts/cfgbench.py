@@ -85,6 +85,30 @@ def main():
                        "partition_conv_equals_whole": bool(ok_cv), "partition_hists_sum_to_global": bool(ok_h),
                        "partition_equalize_equals_whole": bool(ok_eq)}
         print("cfg5", res["cfg5"], flush=True)
+    if "pcie" in what:
+        # configs[1] with the boundary handing over HOST buffers: pinned H2D of 16 BGR frames, the 3-op step, pinned D2H of
+        # the three outputs (Gaussian BGR, equalized gray, Sobel gray), double-buffered on two streams
+        B, h, w = 16, 2160, 3840
+        hin = [torch.randint(0, 256, (B, h, w, 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        hout = [(torch.empty((B, h, w, 3), dtype=torch.uint8).pin_memory(), torch.empty((B, h, w, 1), dtype=torch.uint8).pin_memory(),
+                 torch.empty((B, h, w, 1), dtype=torch.uint8).pin_memory()) for _ in range(2)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        def run(iters):
+            for it in range(iters):
+                k = it & 1
+                with torch.cuda.stream(streams[k]):
+                    d = hin[k].to(dev, non_blocking=True)
+                    g5 = ops.gaussian_blur(d, 5)
+                    gray, eq = ops.bgr2gray_equalize(d)
+                    sb = ops.sobel(gray)
+                    hout[k][0].copy_(g5, non_blocking=True); hout[k][1].copy_(eq, non_blocking=True); hout[k][2].copy_(sb, non_blocking=True)
+            torch.cuda.synchronize()
+        run(2)
+        import time
+        t0 = time.perf_counter(); run(8); dt = (time.perf_counter() - t0) / 8
+        res["cfg2_host_buffers"] = {"ms_per_16_frames": round(dt * 1e3, 2), "MP_per_s": round(B * h * w / 1e6 / dt, 1),
+                                    "host_GBps": round((B * h * w * (3 + 3 + 1 + 1)) / dt / 1e9, 1)}
+        print("pcie", res["cfg2_host_buffers"], flush=True)
     print(json.dumps(res))
 
 
