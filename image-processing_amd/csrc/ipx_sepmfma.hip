@@ -64,7 +64,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ v4i lds16(const uint8_t* p) { return *reinterpret_cast<const v4i*>(p); }
 
-template <int C, int HL>
+template <int C, int HL, int NMT>                               // NMT: 16-row tiles of the row pass (5 for k <= 17, else 6)
 __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                MGeom g, MTaps taps)
 {
@@ -207,7 +207,6 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
     const uint8_t* const r_out = s_out + orow * kPitchO + 16 * occ;
     const unsigned ooff = (unsigned)(orow * (int)g.d_row + 16 * occ);
 
-    const int MT = (RY + 15) / 16;
     int pslot = 0;
     auto stamp = [&]() { if (g.prof && blockIdx.x == 0 && tid == 0 && pslot < 64) g.prof[pslot++] = (long long)__builtin_readcyclecounter(); };
     stamp();
@@ -226,9 +225,11 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
     if (!live) return;
 
     // ---- 2. row pass: wave w owns column tile w (16 output columns) of every 16-row tile ----------------------
+    // NMT whole 16-row tiles, also when fewer source rows exist (rows >= RY hold stale bytes that only meet zero taps):
+    // no branch inside the unrolled loop, so the LDS reads of later tiles overlap the MFMAs and epilogues of earlier ones
+    if (!(g.ablate & 2))
 #pragma unroll
-    for (int mt = 0; mt < kRowsS / 16; ++mt) {
-        if (mt >= MT || (g.ablate & 2)) break;
+    for (int mt = 0; mt < NMT; ++mt) {
         v4i acc = {0, 0, 0, 0};
 #pragma unroll
         for (int ks = 0; ks < KSH; ++ks)
@@ -297,12 +298,19 @@ void launch_c(hipStream_t st, const uint8_t* src, uint8_t* dst, const MGeom& g, 
 {
     const int hl = (g.r * C + 15) & ~15;
     const dim3 grid(8u * (unsigned)(g.pw * g.ph)), block(kThreads);
+    const bool five = 64 + 2 * g.r <= 80;
+#define IPX_MFMA_LAUNCH(HLV)                                                                                               \
+    do {                                                                                                                   \
+        if (five) hipLaunchKernelGGL((sep_mfma_kernel<C, HLV, 5>), grid, block, 0, st, src, dst, g, t);                     \
+        else hipLaunchKernelGGL((sep_mfma_kernel<C, HLV, 6>), grid, block, 0, st, src, dst, g, t);                          \
+    } while (0)
     switch (hl) {
-        case 16: hipLaunchKernelGGL((sep_mfma_kernel<C, 16>), grid, block, 0, st, src, dst, g, t); break;
-        case 32: hipLaunchKernelGGL((sep_mfma_kernel<C, 32>), grid, block, 0, st, src, dst, g, t); break;
-        case 48: hipLaunchKernelGGL((sep_mfma_kernel<C, 48>), grid, block, 0, st, src, dst, g, t); break;
-        default: hipLaunchKernelGGL((sep_mfma_kernel<C, 64>), grid, block, 0, st, src, dst, g, t); break;
+        case 16: IPX_MFMA_LAUNCH(16); break;
+        case 32: IPX_MFMA_LAUNCH(32); break;
+        case 48: IPX_MFMA_LAUNCH(48); break;
+        default: IPX_MFMA_LAUNCH(64); break;
     }
+#undef IPX_MFMA_LAUNCH
 }
 
 }  // namespace
