@@ -13,14 +13,16 @@
  *    calling thread's current HIP device.  The caller owns every buffer; the library never frees
  *    caller memory.  src and dst must not overlap unless an entry point says in-place is allowed.
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is enqueued on
- *    it; no entry point synchronises the device.  The library keeps no mutable global state, so
+ *    it; no entry point synchronises the device except ipx_pairwise_sum_lut_f32, whose result is a
+ *    host scalar (it says so).  The library keeps no mutable global state, so
  *    concurrent calls from different host threads (Flask workers, one thread per GPU) are safe as
  *    long as they do not share output buffers.
  *  - Images are uint8, C-contiguous inside a row, channels interleaved (BGR order where it matters),
  *    as in the reference (H x W or H x W x 3 numpy arrays).  A batch is `n` images of identical
  *    geometry; image i starts at base + i*img_stride bytes and row y at + y*row_stride bytes.
  *    row_stride >= w*c; strides are in bytes.
- *  - Borders are OpenCV's BORDER_DEFAULT (BORDER_REFLECT_101) everywhere, as in the reference.
+ *  - Convolution borders are OpenCV's BORDER_DEFAULT (BORDER_REFLECT_101), as in the reference; the
+ *    rank / morphological / Lee filters follow the border rule of the call they replace (stated there).
  *    Convolutions accept optional halo rows (`top_halo` / `bottom_halo`, `r` rows each with the
  *    source row stride, NULL = reflect at the image edge) so that a row-partitioned giant image can be
  *    filtered shard by shard after a halo exchange.
