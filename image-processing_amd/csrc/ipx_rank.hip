@@ -2,8 +2,9 @@
 // mode=denoise_manual with method=median (server.py:214-216).  SURVEY.md section 8(f) row 4.  Gray images.
 //
 //   cv2.medianBlur(img, k)        uint8, odd k (3..31 here), BORDER_REPLICATE: the (k*k-1)/2-th smallest of the k x k
-//                                 window.  Exact integer result, so any algorithm agrees: here an 8-step binary search on
-//                                 the value, counting window pixels <= mid from an LDS tile (8 k^2 compares per pixel).
+//                                 window.  Exact integer result, so any algorithm agrees: k = 3, 5, 7 run a selection
+//                                 network in registers (two pixels per thread, packed 16-bit min/max); larger k an 8-step
+//                                 binary search on the value, counting window pixels <= mid from an LDS tile.
 //   cv2.erode / cv2.dilate        min / max over the structuring element's non-zero positions (anchor = centre); pixels
 //                                 outside the image are ignored (OpenCV's default border value: +inf for erode, -inf for
 //                                 dilate).  cv2.morphologyEx OPEN = dilate(erode), CLOSE = erode(dilate): composed by the
@@ -68,6 +69,95 @@ __global__ __launch_bounds__(kTileW * kTileH) void median_kernel(const uint8_t* 
     dst[(int64_t)img * g.d_img + (int64_t)y * g.d_row + x] = (uint8_t)lo;
 }
 
+// ---- median for k = 3, 5, 7: forgetful selection in registers ----------------------------------------------------
+// A thread owns two horizontally adjacent pixels and keeps their window values as packed 16-bit pairs, so every
+// compare-exchange is one v_pk_min_u16 + one v_pk_max_u16 for both pixels.  Forgetful selection: the median of n values
+// can never be the minimum or the maximum of any n/2 + 2 of them, so start with n/2 + 2 values, drop their min and max,
+// take in the next value, and repeat until three are left; their middle one is the median.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void cswap(us2& a, us2& b)             // a <- min, b <- max (per 16-bit half)
+{
+    const us2 lo = __builtin_elementwise_min(a, b), hi = __builtin_elementwise_max(a, b);
+    a = lo;
+    b = hi;
+}
+
+template <int CNT>
+__device__ __forceinline__ void min_max_to_ends(us2 (&v)[CNT])   // v[0] <- min, v[CNT-1] <- max of v[0..CNT)
+{
+#pragma unroll
+    for (int i = 0; i < CNT / 2; ++i) cswap(v[i], v[CNT - 1 - i]);
+#pragma unroll
+    for (int i = 1; i < (CNT + 1) / 2; ++i) cswap(v[0], v[i]);
+#pragma unroll
+    for (int i = CNT / 2; i < CNT - 1; ++i) cswap(v[i], v[CNT - 1]);
+}
+
+template <int CNT, int N, typename NextFn>
+struct Forget {
+    static __device__ __forceinline__ us2 run(us2 (&v)[CNT], int next, NextFn& fetch)
+    {
+        min_max_to_ends<CNT>(v);
+        us2 w[CNT - 1];
+        w[0] = fetch(next);                                       // replaces the minimum; the maximum falls off the end
+#pragma unroll
+        for (int i = 1; i < CNT - 1; ++i) w[i] = v[i];
+        return Forget<CNT - 1, N, NextFn>::run(w, next + 1, fetch);
+    }
+};
+template <int N, typename NextFn>
+struct Forget<3, N, NextFn> {
+    static __device__ __forceinline__ us2 run(us2 (&v)[3], int, NextFn&)
+    {
+        min_max_to_ends<3>(v);
+        return v[1];
+    }
+};
+
+constexpr int kSmW = 64, kSmH = 8;                               // 64 x 8 pixel tile, 2 pixels per thread
+constexpr int kSmPitch = kSmW + 2 * 3 + 2;                       // 72
+
+template <int K>
+__global__ __launch_bounds__(256) void median_small_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, RankGeom g)
+{
+    constexpr int R = K / 2, N = K * K, M = N / 2 + 2;
+    __shared__ uint8_t s_tile[(kSmH + 2 * R) * kSmPitch];
+    const unsigned tile = blockIdx.x;
+    const int tx0 = (int)(tile % (unsigned)g.tiles_x) * kSmW;
+    const int ty0 = (int)(tile / (unsigned)g.tiles_x % (unsigned)g.tiles_y) * kSmH;
+    const unsigned img = tile / ((unsigned)g.tiles_x * (unsigned)g.tiles_y);
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    const int tid = (int)threadIdx.x;
+    constexpr int tw = kSmW + 2 * R, th = kSmH + 2 * R;
+    for (int i = tid; i < tw * th; i += 256) {                   // BORDER_REPLICATE: clamp the coordinates
+        const int ry = i / tw, rx = i - ry * tw;
+        int y = ty0 - R + ry, x = tx0 - R + rx;
+        y = y < 0 ? 0 : y >= g.h ? g.h - 1 : y;
+        x = x < 0 ? 0 : x >= g.w ? g.w - 1 : x;
+        s_tile[ry * kSmPitch + rx] = simg[(int64_t)y * g.s_row + x];
+    }
+    __syncthreads();
+    const int lx = 2 * (tid % (kSmW / 2)), ly = tid / (kSmW / 2);
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x >= g.w || y >= g.h) return;
+    const uint8_t* base = s_tile + ly * kSmPitch + lx;
+    auto fetch = [&](int i) {                                     // window value i of pixel x (low half) and x+1 (high half)
+        const uint8_t* p = base + (i / K) * kSmPitch + (i % K);
+        us2 r;
+        r.x = p[0];
+        r.y = p[1];
+        return r;
+    };
+    us2 v[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) v[i] = fetch(i);
+    const us2 med = Forget<M, N, decltype(fetch)>::run(v, M, fetch);
+    uint8_t* dp = dst + (int64_t)img * g.d_img + (int64_t)y * g.d_row + x;
+    dp[0] = (uint8_t)med.x;
+    if (x + 1 < g.w) dp[1] = (uint8_t)med.y;
+}
+
 template <bool DILATE>
 __global__ __launch_bounds__(kTileW * kTileH) void morph_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, RankGeom g, SeMask se)
 {
@@ -130,6 +220,18 @@ int ipx_median_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, in
     RankGeom g;
     unsigned blocks = 0;
     if (int rc = make_geom(fn, g, src, dst, n, h, w, k / 2, k / 2, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride, &blocks)) return rc;
+    if (k == 3 || k == 5 || k == 7) {                             // register selection network, 2 pixels per thread
+        g.tiles_x = (w + kSmW - 1) / kSmW;
+        g.tiles_y = (h + kSmH - 1) / kSmH;
+        const uint64_t nb = (uint64_t)n * g.tiles_x * g.tiles_y;
+        if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many tiles", fn);
+        const dim3 grid((unsigned)nb), block(256);
+        if (k == 3) hipLaunchKernelGGL(median_small_kernel<3>, grid, block, 0, (hipStream_t)stream, src, dst, g);
+        else if (k == 5) hipLaunchKernelGGL(median_small_kernel<5>, grid, block, 0, (hipStream_t)stream, src, dst, g);
+        else hipLaunchKernelGGL(median_small_kernel<7>, grid, block, 0, (hipStream_t)stream, src, dst, g);
+        IPX_LAUNCH_CHECK("median_small_kernel");
+        return IPX_OK;
+    }
     hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(kTileW * kTileH), 0, (hipStream_t)stream, src, dst, g);
     IPX_LAUNCH_CHECK("median_kernel");
     return IPX_OK;

@@ -61,6 +61,16 @@ def main():
             g1 = gray[:1]
             s = time_op(lambda: ops.lee_filter(g1, wnd), reps=5)
             print(f"lee w={wnd:2d} one 4K gray frame {s*1e6:9.1f} us  {H*W/s/1e6:9.1f} MP/s", flush=True)
+    if "median" in what:
+        g1 = gray[:1]
+        for k in (3, 5, 9, 15, 31):
+            s = time_op(lambda: ops.median_blur(g1, k), reps=3)
+            print(f"median k={k:2d} one 4K gray frame {s*1e6:9.1f} us  {H*W/s/1e6:9.1f} MP/s", flush=True)
+        se = ops.ellipse_se(5)
+        s = time_op(lambda: ops.morph_close(ops.morph_open(g1, se), se), reps=3)
+        print(f"open+close 5x5 ellipse one 4K gray frame {s*1e6:9.1f} us", flush=True)
+        s = time_op(lambda: ops.denoise_stats(g1[0, :, :, 0], "lee"), reps=3)
+        print(f"denoise_stats one 4K gray frame (blocking, 2 host round trips) {s*1e6:9.1f} us", flush=True)
     if "eq" in what:
         for nb in (1, 2, 4, 8, 16):
             if nb > B: break
