@@ -39,43 +39,132 @@ __device__ __forceinline__ void load_tile(uint8_t* s_tile, const uint8_t* simg, 
     }
 }
 
-__global__ __launch_bounds__(kTileW * kTileH) void median_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, RankGeom g)
+// ---- median for k >= 11: sliding histograms (constant work per pixel, whatever k) --------------------------------
+// One wave owns a strip of 64 output columns and walks down a band of rows.  LDS holds one 256-bin byte histogram per
+// strip column (64 + 2r of them), each over the 2r+1 rows around the current one; stepping down a row takes one pixel
+// out of and puts one into every column histogram (a lane per column).  Along a row the window histogram lives in
+// registers, four 16-bit bins per lane: moving right adds the entering column's histogram and subtracts the leaving
+// one's (one conflict-free dword read each), then a wave prefix sum over the lane totals finds the lane and, inside
+// it, the bin where the running count first reaches (k*k)/2 + 1.
+// Column c's dwords are rotated by c, so that lanes bumping the same value in 64 different columns hit 64 banks.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+constexpr int kHsW = 64;
+
+__device__ __forceinline__ int wave_inclusive_scan(int v)
 {
-    __shared__ uint8_t s_tile[(kTileH + 2 * kMaxR) * kPitch];
-    const unsigned tile = blockIdx.x;
-    const int tx0 = (int)(tile % (unsigned)g.tiles_x) * kTileW;
-    const int ty0 = (int)(tile / (unsigned)g.tiles_x % (unsigned)g.tiles_y) * kTileH;
-    const unsigned img = tile / ((unsigned)g.tiles_x * (unsigned)g.tiles_y);
-    const int tid = (int)threadIdx.x;
-    load_tile<-1>(s_tile, src + (int64_t)img * g.s_img, g, tx0, ty0, tid);
-    __syncthreads();
-    const int lx = tid % kTileW, ly = tid / kTileW;
-    const int x = tx0 + lx, y = ty0 + ly;
-    if (x >= g.w || y >= g.h) return;
-    const int K = 2 * g.rx + 1;
-    const int need = (K * K) / 2 + 1;                      // the median is the smallest v with count(<= v) >= need
-    const uint8_t* base = s_tile + ly * kPitch + lx;
-    int lo = 0, hi = 255;
-#pragma unroll 1
-    for (int step = 0; step < 8; ++step) {
-        const int mid = (lo + hi) >> 1;
-        int cnt = 0;
-        for (int wy = 0; wy < K; ++wy) {
-            const uint8_t* rp = base + wy * kPitch;
-            for (int wx = 0; wx < K; ++wx) cnt += rp[wx] <= mid ? 1 : 0;
-        }
-        if (cnt >= need) hi = mid; else lo = mid + 1;
-    }
-    dst[(int64_t)img * g.d_img + (int64_t)y * g.d_row + x] = (uint8_t)lo;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8   -> scan inside each row of 16
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
 }
 
-// ---- median for k = 3, 5, 7: forgetful selection in registers ----------------------------------------------------
+__device__ __forceinline__ us2 bins_lo(uint32_t d) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, d, 0x0c010c00u)); }
+__device__ __forceinline__ us2 bins_hi(uint32_t d) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, d, 0x0c030c02u)); }
+
+__device__ __forceinline__ int find_rank(us2 h01, us2 h23, int need, int lane)
+{
+    const us2 ones = {1, 1};
+    const int t = (int)__builtin_amdgcn_udot2(h01, ones, __builtin_amdgcn_udot2(h23, ones, 0u, false), false);
+    const int p = wave_inclusive_scan(t);
+    const uint64_t reached = __ballot(p >= need);                    // never empty: lane 63 holds k*k
+    const int L = (int)__builtin_ctzll(reached);
+    const int below = __builtin_amdgcn_readlane(p - t, L);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint32_t, h01), L);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint32_t, h23), L);
+    const int c0 = below + (int)(a & 0xffffu), c1 = c0 + (int)(a >> 16), c2 = c1 + (int)(b & 0xffffu);
+    (void)lane;
+    return 4 * L + (c0 < need) + (c1 < need) + (c2 < need);
+}
+
+__global__ __launch_bounds__(64) void median_hist_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, RankGeom g, int band_rows)
+{
+    extern __shared__ uint32_t s_hist[];                            // (64 + 2r) columns x 256 byte bins
+    uint8_t* hb = (uint8_t*)s_hist;
+    const unsigned tile = blockIdx.x;
+    const int x0 = (int)(tile % (unsigned)g.tiles_x) * kHsW;
+    const int y0 = (int)(tile / (unsigned)g.tiles_x % (unsigned)g.tiles_y) * band_rows;
+    const unsigned img = tile / ((unsigned)g.tiles_x * (unsigned)g.tiles_y);
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    const int lane = (int)threadIdx.x;
+    const int r = g.rx, K = 2 * r + 1, nc = kHsW + 2 * r, need = (K * K) / 2 + 1;
+    const int y1 = y0 + band_rows < g.h ? y0 + band_rows : g.h;
+    const int nout = g.w - x0 < kHsW ? g.w - x0 : kHsW;
+
+    // the (up to) two columns whose histograms this lane maintains
+    int xc[2];
+    bool own[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int c = lane + 64 * q;
+        own[q] = c < nc;
+        const int x = x0 - r + c;
+        xc[q] = x < 0 ? 0 : x >= g.w ? g.w - 1 : x;                   // BORDER_REPLICATE
+    }
+    auto bin_addr = [&](int q, int v) { const int c = lane + 64 * q; return c * 256 + ((((v >> 2) + c) & 63) << 2) + (v & 3); };
+    auto row_of = [&](int y) { return (int64_t)(y < 0 ? 0 : y >= g.h ? g.h - 1 : y) * g.s_row; };
+
+    for (int i = lane; i < nc * 64; i += 64) s_hist[i] = 0u;
+    __syncthreads();
+    for (int j = -r; j <= r; ++j) {
+        const int64_t ro = row_of(y0 + j);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int v = simg[ro + xc[q]];
+            if (own[q]) hb[bin_addr(q, v)] += 1;
+        }
+    }
+    __syncthreads();
+
+    for (int y = y0; y < y1; ++y) {
+        // the pixels that leave and enter the column histograms after this row (loaded early, used after the row)
+        int ov[2], nv[2];
+        {
+            const int64_t ro = row_of(y - r), rn = row_of(y + r + 1);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { ov[q] = simg[ro + xc[q]]; nv[q] = simg[rn + xc[q]]; }
+        }
+        us2 h01 = {0, 0}, h23 = {0, 0};
+        for (int c = 0; c < K; ++c) {
+            const uint32_t d = s_hist[c * 64 + ((lane + c) & 63)];
+            h01 += bins_lo(d);
+            h23 += bins_hi(d);
+        }
+        int res = find_rank(h01, h23, need, lane);
+        auto column = [&](int c) { c = c < nc ? c : nc - 1; return s_hist[c * 64 + ((lane + c) & 63)]; };
+        uint32_t d_new = column(1 + 2 * r), d_old = column(0);
+#pragma unroll 2
+        for (int i = 1; i < nout; ++i) {
+            const uint32_t d_new2 = column(i + 1 + 2 * r), d_old2 = column(i);   // next step's, in flight during the search
+            h01 = h01 + bins_lo(d_new) - bins_lo(d_old);
+            h23 = h23 + bins_hi(d_new) - bins_hi(d_old);
+            const int m = find_rank(h01, h23, need, lane);
+            res = lane == i ? m : res;
+            d_new = d_new2;
+            d_old = d_old2;
+        }
+        if (lane < nout) dimg[(int64_t)y * g.d_row + x0 + lane] = (uint8_t)res;
+        __syncthreads();
+        if (y + 1 < y1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (own[q]) {
+                    hb[bin_addr(q, ov[q])] -= 1;
+                    hb[bin_addr(q, nv[q])] += 1;
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- median for k = 3, 5, 7, 9: forgetful selection in registers ----------------------------------------------------
 // A thread owns two horizontally adjacent pixels and keeps their window values as packed 16-bit pairs, so every
 // compare-exchange is one v_pk_min_u16 + one v_pk_max_u16 for both pixels.  Forgetful selection: the median of n values
 // can never be the minimum or the maximum of any n/2 + 2 of them, so start with n/2 + 2 values, drop their min and max,
 // take in the next value, and repeat until three are left; their middle one is the median.
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ void cswap(us2& a, us2& b)             // a <- min, b <- max (per 16-bit half)
 {
     const us2 lo = __builtin_elementwise_min(a, b), hi = __builtin_elementwise_max(a, b);
@@ -116,12 +205,12 @@ struct Forget<3, N, NextFn> {
 };
 
 constexpr int kSmW = 64, kSmH = 8;                               // 64 x 8 pixel tile, 2 pixels per thread
-constexpr int kSmPitch = kSmW + 2 * 3 + 2;                       // 72
+constexpr int kSmPitch = kSmW + 2 * 4 + 4;                       // 76
 
 template <int K>
 __global__ __launch_bounds__(256) void median_small_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, RankGeom g)
 {
-    constexpr int R = K / 2, N = K * K, M = N / 2 + 2;
+    constexpr int R = K / 2, N = K * K, M = K == 1 ? 3 : N / 2 + 2;
     __shared__ uint8_t s_tile[(kSmH + 2 * R) * kSmPitch];
     const unsigned tile = blockIdx.x;
     const int tx0 = (int)(tile % (unsigned)g.tiles_x) * kSmW;
@@ -149,10 +238,15 @@ __global__ __launch_bounds__(256) void median_small_kernel(const uint8_t* __rest
         r.y = p[1];
         return r;
     };
-    us2 v[M];
+    us2 med;
+    if constexpr (K == 1) {
+        med = fetch(0);
+    } else {
+        us2 v[M];
 #pragma unroll
-    for (int i = 0; i < M; ++i) v[i] = fetch(i);
-    const us2 med = Forget<M, N, decltype(fetch)>::run(v, M, fetch);
+        for (int i = 0; i < M; ++i) v[i] = fetch(i);
+        med = Forget<M, N, decltype(fetch)>::run(v, M, fetch);
+    }
     uint8_t* dp = dst + (int64_t)img * g.d_img + (int64_t)y * g.d_row + x;
     dp[0] = (uint8_t)med.x;
     if (x + 1 < g.w) dp[1] = (uint8_t)med.y;
@@ -220,20 +314,36 @@ int ipx_median_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, in
     RankGeom g;
     unsigned blocks = 0;
     if (int rc = make_geom(fn, g, src, dst, n, h, w, k / 2, k / 2, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride, &blocks)) return rc;
-    if (k == 3 || k == 5 || k == 7) {                             // register selection network, 2 pixels per thread
+    if (k <= 9) {                                                 // register selection network, 2 pixels per thread
         g.tiles_x = (w + kSmW - 1) / kSmW;
         g.tiles_y = (h + kSmH - 1) / kSmH;
         const uint64_t nb = (uint64_t)n * g.tiles_x * g.tiles_y;
         if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many tiles", fn);
         const dim3 grid((unsigned)nb), block(256);
-        if (k == 3) hipLaunchKernelGGL(median_small_kernel<3>, grid, block, 0, (hipStream_t)stream, src, dst, g);
-        else if (k == 5) hipLaunchKernelGGL(median_small_kernel<5>, grid, block, 0, (hipStream_t)stream, src, dst, g);
-        else hipLaunchKernelGGL(median_small_kernel<7>, grid, block, 0, (hipStream_t)stream, src, dst, g);
+        switch (k) {
+        case 1: hipLaunchKernelGGL(median_small_kernel<1>, grid, block, 0, (hipStream_t)stream, src, dst, g); break;
+        case 3: hipLaunchKernelGGL(median_small_kernel<3>, grid, block, 0, (hipStream_t)stream, src, dst, g); break;
+        case 5: hipLaunchKernelGGL(median_small_kernel<5>, grid, block, 0, (hipStream_t)stream, src, dst, g); break;
+        case 7: hipLaunchKernelGGL(median_small_kernel<7>, grid, block, 0, (hipStream_t)stream, src, dst, g); break;
+        default: hipLaunchKernelGGL(median_small_kernel<9>, grid, block, 0, (hipStream_t)stream, src, dst, g); break;
+        }
         IPX_LAUNCH_CHECK("median_small_kernel");
         return IPX_OK;
     }
-    hipLaunchKernelGGL(median_kernel, dim3(blocks), dim3(kTileW * kTileH), 0, (hipStream_t)stream, src, dst, g);
-    IPX_LAUNCH_CHECK("median_kernel");
+    // sliding histograms: a wave per 64-column strip and row band; bands sized to give the chip a few thousand waves,
+    // but never much shorter than the k rows it costs to set a band's histograms up
+    const int strips = (w + kHsW - 1) / kHsW;
+    int bands = (int)((4096 + (int64_t)strips * n - 1) / ((int64_t)strips * n));
+    const int min_rows = k > 16 ? k : 16;
+    if (bands > (h + min_rows - 1) / min_rows) bands = (h + min_rows - 1) / min_rows;
+    if (bands < 1) bands = 1;
+    const int band_rows = (h + bands - 1) / bands;
+    g.tiles_x = strips;
+    g.tiles_y = (h + band_rows - 1) / band_rows;
+    const uint64_t nb = (uint64_t)n * g.tiles_x * g.tiles_y;
+    if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many tiles", fn);
+    hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)nb), dim3(64), (size_t)(kHsW + k - 1) * 256, (hipStream_t)stream, src, dst, g, band_rows);
+    IPX_LAUNCH_CHECK("median_hist_kernel");
     return IPX_OK;
 }
 

@@ -326,6 +326,20 @@ def test_median_extremes_and_batch(dev):
         np.testing.assert_array_equal(got[i, :, :, 0], O.median_blur_u8(batch[i, :, :, 0], 5))
 
 
+@pytest.mark.parametrize("k", [9, 11, 13, 21, 31])
+def test_median_many_strips_and_bands(dev, k):
+    """Several 64-column strips and row bands per image, a strided batch, flat regions (all lanes bump one bin)."""
+    rng = np.random.default_rng(k)
+    batch = rng.integers(0, 256, (2, 300, 333, 1), dtype=np.uint8)
+    batch[0, 40:120, 50:300] = 200                                   # flat patch wider than a strip
+    batch[1, :, :, 0] = (batch[1, :, :, 0] // 64) * 64                # four grey levels only
+    got = host(ops.median_blur(dev_t(batch, dev), k))
+    for i in range(2):
+        np.testing.assert_array_equal(got[i, :, :, 0], O.median_blur_u8(batch[i, :, :, 0], k))
+    wide = rng.integers(0, 256, (40, 2100), dtype=np.uint8)          # one band, 33 strips
+    np.testing.assert_array_equal(host(ops.median_blur(dev_t(wide, dev), k)), O.median_blur_u8(wide, k))
+
+
 @pytest.mark.parametrize("shape", [(1, 1), (4, 9), (33, 70), (64, 97)])
 @pytest.mark.parametrize("m", [1, 3, 5, 7, 15, 31])
 def test_morphology(dev, shape, m):
