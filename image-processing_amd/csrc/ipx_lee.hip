@@ -10,10 +10,22 @@
 //   * window.var(): x = fl(v - mean), x = fl(x * x), then numpy's PAIRWISE float32 sum over the n = (2k+1)^2 values in
 //     row-major window order (blocks of <= 128 values summed with 8 interleaved accumulators, combined as a tree,
 //     remainder added serially; larger n split recursively at n/2 rounded down to a multiple of 8), then fl(sum / n).
-// Every float operation below is an explicit round-to-nearest intrinsic (no FMA contraction).  mean_w**2 on a numpy
+// Every float operation below is a separately rounded operation (no FMA contraction, see rn_add etc.).  mean_w**2 on a numpy
 // float32 scalar is powf(x, 2.0f); it is taken to be fl(x * x) here (what correctly rounded powf returns).
 // One thread per pixel; the block's (8 + 2k) x (32 + 2k) source tile and the window's offset table sit in LDS.
 #include "ipx_common.h"
+
+// numpy rounds after every operation: a*b+c must never be fused into one FMA.  In this HIP version the __f*_rn
+// intrinsics are plain operators defined in a header, i.e. compiled under the default -ffp-contract=fast, and the
+// backend did fuse them (v_fmac_f32 in the variance sum: one result in ~3 million off by one).  So: operators of our own,
+// defined under contract(off).
+#pragma clang fp contract(off)
+namespace {
+__device__ __forceinline__ float rn_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float rn_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float rn_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float rn_div(float a, float b) { return a / b; }     // IEEE: HIP's default is the correctly rounded one
+}  // namespace
 
 namespace {
 
@@ -33,8 +45,8 @@ struct Win {                                               // what a thread need
     float mean;
     __device__ __forceinline__ float sq(int i) const
     {
-        const float d = __fsub_rn((float)base[pos[i]], mean);
-        return __fmul_rn(d, d);
+        const float d = rn_sub((float)base[pos[i]], mean);
+        return rn_mul(d, d);
     }
 };
 
@@ -43,7 +55,7 @@ __device__ __forceinline__ float pw_block(const Win& wv, int off, int n)
 {
     if (n < 8) {
         float res = 0.f;
-        for (int i = 0; i < n; ++i) res = __fadd_rn(res, wv.sq(off + i));
+        for (int i = 0; i < n; ++i) res = rn_add(res, wv.sq(off + i));
         return res;
     }
     float r[8];
@@ -52,11 +64,11 @@ __device__ __forceinline__ float pw_block(const Win& wv, int off, int n)
     int i = 8;
     for (; i < n - (n % 8); i += 8) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], wv.sq(off + i + j));
+        for (int j = 0; j < 8; ++j) r[j] = rn_add(r[j], wv.sq(off + i + j));
     }
-    float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])),
-                          __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
-    for (; i < n; ++i) res = __fadd_rn(res, wv.sq(off + i));
+    float res = rn_add(rn_add(rn_add(r[0], r[1]), rn_add(r[2], r[3])),
+                          rn_add(rn_add(r[4], r[5]), rn_add(r[6], r[7])));
+    for (; i < n; ++i) res = rn_add(res, wv.sq(off + i));
     return res;
 }
 
@@ -72,7 +84,7 @@ __device__ __forceinline__ float pw_sum(const Win& wv, int off, int n)
         n2 -= n2 % 8;
         const float a = pw_sum<DEPTH - 1>(wv, off, n2);
         const float b = pw_sum<DEPTH - 1>(wv, off + n2, n - n2);
-        return __fadd_rn(a, b);
+        return rn_add(a, b);
     }
 }
 
@@ -111,14 +123,14 @@ __global__ __launch_bounds__(kTileW * kTileH) void lee_kernel(const uint8_t* __r
         uint32_t isum = 0;
         for (int i = 0; i < n; ++i) isum += wv.base[s_pos[i]];
         const float fn = (float)n;
-        const float mean = __fdiv_rn((float)isum, fn);
+        const float mean = rn_div((float)isum, fn);
         wv.mean = mean;
-        const float var = __fdiv_rn(pw_sum<3>(wv, 0, n), fn);
+        const float var = rn_div(pw_sum<3>(wv, 0, n), fn);
         float o;
         if (var > 0.f) {
-            const float q = __fdiv_rn(__fmul_rn(mean, mean), __fadd_rn(mean, 1e-12f));
-            const float k_lee = __fdiv_rn(var, __fadd_rn(var, q));
-            o = __fadd_rn(mean, __fmul_rn(k_lee, __fsub_rn((float)centre, mean)));
+            const float q = rn_div(rn_mul(mean, mean), rn_add(mean, 1e-12f));
+            const float k_lee = rn_div(var, rn_add(var, q));
+            o = rn_add(mean, rn_mul(k_lee, rn_sub((float)centre, mean)));
         } else {
             o = mean;
         }

@@ -12,6 +12,10 @@
 //   the host adds the buffer sums in sequence (float32) and evaluates the ragged last buffer itself (same recursion).
 // Verified against numpy in tests/ (oracle/oracle.py pairwise_sum_f32 == np.add.reduce on this image's numpy).
 #include "ipx_common.h"
+
+// numpy rounds after every operation: a*b+c must never be fused into one FMA (in this HIP version the __f*_rn
+// intrinsics are plain operators, which the default -ffp-contract=fast would contract)
+#pragma clang fp contract(off)
 #include <vector>
 
 namespace {

@@ -164,6 +164,17 @@ def main():
     for wnd in (9, 15, 31):                     # large windows: numpy's pairwise sum recurses above 128 values
         arrays[f"out_lee_rand_{wnd}"] = server.lee_filter(imgs["rand"], window_size=wnd)
 
+    # 3 x 3 windows whose result changes by one if the variance sum or the final mean + k * (x - mean) is evaluated
+    # with a fused multiply-add (found by random search): the reference rounds after every operation
+    patches = [[173, 164, 234, 228, 51, 90, 114, 55, 200], [173, 117, 174, 25, 49, 172, 219, 250, 227],
+               [107, 151, 63, 80, 21, 81, 193, 46, 245], [150, 192, 9, 185, 222, 107, 11, 201, 167],
+               [163, 81, 254, 11, 236, 136, 164, 72, 18], [245, 7, 10, 77, 199, 14, 197, 186, 224],
+               [74, 139, 114, 128, 4, 62, 186, 43, 168], [60, 195, 22, 25, 4, 161, 123, 140, 170],
+               [231, 116, 145, 140, 43, 218, 48, 87, 49], [253, 55, 90, 42, 208, 160, 182, 98, 66],
+               [182, 97, 153, 177, 28, 143, 58, 224, 162], [107, 204, 129, 244, 17, 226, 67, 90, 23]]
+    arrays["in_lee_rounding"] = np.concatenate([np.array(p_, np.uint8).reshape(3, 3) for p_ in patches], axis=1)
+    arrays["out_lee_rounding_3"] = server.lee_filter(arrays["in_lee_rounding"], window_size=3)
+
     # mode=denoise_manual with method=lee through the real dispatch (server.py:181-241): histogram statistics
     # (extreme_ratio, variance, cv, suggested_method) and the Lee output, all numpy inside the reference
     sp = imgs["rand"].copy()

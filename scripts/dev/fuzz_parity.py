@@ -1,0 +1,132 @@
+"""Dev tool (GPU box): randomized parity sweep of the HIP library against the CPU oracle.
+
+Random shapes (incl. widths around the 16-byte / 1 KiB strip / 128-byte tile edges), channel counts, batch sizes and
+ROW-STRIDED views (a window of a wider buffer), every operator.  Exact equality everywhere.  The fixed-shape cases live
+in tests/test_gpu_parity.py; this looks for the shapes nobody thought of.
+usage: python scripts/dev/fuzz_parity.py [--seconds 90] [--seed 0] [--ops lee,median]"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+for p in ("image-processing_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np
+import torch
+
+import oracle as O
+from ipx import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=90)
+ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--ops", default="gray,lut,eq,grayeq,sharpen,box3,sobel,gauss,gauss,lee,median,morph")
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+dev = torch.device("cuda:0")
+
+EDGE_W = [1, 2, 5, 15, 16, 17, 31, 33, 63, 64, 65, 127, 128, 129, 341, 342, 343, 1023, 1024, 1025, 1365, 2047, 2049]
+
+
+def rand_shape(max_px=400_000):
+    w = int(rng.choice(EDGE_W)) if rng.random() < 0.5 else int(rng.integers(1, 2200))
+    h = int(rng.integers(1, max(2, min(300, max_px // w))))
+    return h, w
+
+
+def make(n, h, w, c, strided):
+    """device tensor (n, h, w, c) -- optionally a window of a wider / taller buffer -- and its numpy value"""
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        img = rng.integers(0, 256, (n, h, w, c), dtype=np.uint8)
+    elif kind == 1:
+        img = (rng.integers(0, 2, (n, h, w, c)) * 255).astype(np.uint8)
+    elif kind == 2:
+        img = np.clip(rng.normal(128, 12, (n, h, w, c)), 0, 255).astype(np.uint8)
+    else:
+        img = np.full((n, h, w, c), int(rng.integers(0, 256)), np.uint8)
+    if not strided:
+        return torch.from_numpy(img).to(dev), img
+    px, py = int(rng.integers(1, 40)), int(rng.integers(0, 3))
+    buf = torch.from_numpy(rng.integers(0, 256, (n, h + py, w + px, c), dtype=np.uint8)).to(dev)
+    x0 = int(rng.integers(0, px + 1))
+    view = buf[:, :h, x0:x0 + w, :]
+    view.copy_(torch.from_numpy(img).to(dev))
+    return view, img
+
+
+def per_image(fn, img):
+    return np.stack([fn(img[i] if img.shape[-1] > 1 else img[i, :, :, 0]).reshape(img.shape[1], img.shape[2], -1)
+                     for i in range(img.shape[0])])
+
+
+def check(name, got, want, info):
+    got = got.cpu().numpy().reshape(want.shape)
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        print(f"MISMATCH {name} {info}: {len(bad)} values, first at {bad[0].tolist()} got {got[tuple(bad[0])]} want {want[tuple(bad[0])]}", flush=True)
+        return 1
+    return 0
+
+
+t_end = time.time() + a.seconds
+cases = fails = 0
+counts = {}
+while time.time() < t_end:
+    op = str(rng.choice(a.ops.split(",")))
+    n = int(rng.integers(1, 4))
+    strided = bool(rng.random() < 0.5)
+    h, w = rand_shape()
+    if op == "gray":
+        c = int(rng.choice([3, 4]))
+        t, img = make(n, h, w, c, strided)
+        fails += check(op, ops.bgr2gray(t), per_image(O.bgr2gray_u8, img), (n, h, w, c, strided))
+    elif op == "lut":
+        c = int(rng.choice([1, 3]))
+        t, img = make(n, h, w, c, strided)
+        lut = rng.permutation(256).astype(np.uint8)
+        fails += check(op, ops.apply_lut(t, lut), lut[img], (n, h, w, c, strided))
+    elif op == "eq":
+        t, img = make(n, h, w, 1, strided)
+        fails += check(op, ops.equalize_hist(t), per_image(O.equalize_hist_u8, img), (n, h, w, strided))
+    elif op == "grayeq":
+        c = int(rng.choice([3, 4]))
+        t, img = make(n, h, w, c, strided)
+        gray, eq = ops.bgr2gray_equalize(t)
+        g = per_image(O.bgr2gray_u8, img)
+        fails += check(op + ".gray", gray, g, (n, h, w, c, strided))
+        fails += check(op + ".eq", eq, per_image(O.equalize_hist_u8, g), (n, h, w, c, strided))
+    elif op in ("sharpen", "box3", "sobel"):
+        c = int(rng.choice([1, 2, 3, 4]))
+        t, img = make(n, h, w, c, strided)
+        fn = {"sharpen": (ops.laplacian_sharpen, O.laplacian_sharpen_u8), "box3": (ops.box3, O.box3_u8), "sobel": (ops.sobel, O.sobel_u8)}[op]
+        fails += check(op, fn[0](t), per_image(fn[1], img), (n, h, w, c, strided))
+    elif op == "gauss":
+        c = int(rng.choice([1, 3, 4]))
+        k = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 17, 21, 25, 31]))
+        t, img = make(n, h, w, c, strided)
+        fails += check(f"gauss{k}", ops.gaussian_blur(t, k), per_image(lambda x: O.gaussian_blur_u8(x, k), img), (n, h, w, c, strided))
+    elif op == "lee":
+        h, w = min(h, 120), min(w, 300)
+        win = int(rng.choice([1, 3, 5, 7, 9, 15, 31]))
+        t, img = make(n, h, w, 1, strided)
+        fails += check(f"lee{win}", ops.lee_filter(t, win), per_image(lambda x: O.lee_filter_u8(x, win), img), (n, h, w, strided))
+    elif op == "median":
+        h, w = min(h, 150), min(w, 700)
+        k = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 21, 31]))
+        t, img = make(n, h, w, 1, strided)
+        fails += check(f"median{k}", ops.median_blur(t, k), per_image(lambda x: O.median_blur_u8(x, k), img), (n, h, w, strided))
+    else:
+        h, w = min(h, 150), min(w, 700)
+        m = int(rng.choice([1, 3, 5, 7, 9, 15, 31]))
+        se = ops.ellipse_se(m)
+        t, img = make(n, h, w, 1, strided)
+        fails += check(f"open{m}", ops.morph_open(t, se), per_image(lambda x: O.morph_open_u8(x, se), img), (n, h, w, strided))
+        fails += check(f"close{m}", ops.morph_close(t, se), per_image(lambda x: O.morph_close_u8(x, se), img), (n, h, w, strided))
+    cases += 1
+    counts[op] = counts.get(op, 0) + 1
+    if cases % 50 == 0:
+        print(f"{cases} cases, {fails} mismatches", flush=True)
+print(f"done: {cases} cases {counts}, {fails} mismatches")
+sys.exit(1 if fails else 0)

@@ -293,6 +293,8 @@ def test_lee_filter_golden_and_batch(dev, golden):
         np.testing.assert_array_equal(host(ops.lee_filter(dev_t(g["in_lee"], dev), w)), g[f"out_lee_{w}"])
     for w in (9, 15, 31):
         np.testing.assert_array_equal(host(ops.lee_filter(dev_t(g["in_rand"], dev), w)), g[f"out_lee_rand_{w}"])
+    # 3 x 3 windows the real server answers differently from an implementation that fuses a multiply into an add
+    np.testing.assert_array_equal(host(ops.lee_filter(dev_t(g["in_lee_rounding"], dev), 3)), g["out_lee_rounding_3"])
     rng = np.random.default_rng(3)
     batch = rng.integers(0, 256, (3, 50, 77, 1), dtype=np.uint8)
     got = host(ops.lee_filter(dev_t(batch, dev), 5))

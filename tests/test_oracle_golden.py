@@ -69,6 +69,8 @@ def test_lee_filter_matches_real_server(golden):
         np.testing.assert_array_equal(O.lee_filter_u8(g["in_lee"], w), g[f"out_lee_{w}"])
     for w in (9, 15, 31):
         np.testing.assert_array_equal(O.lee_filter_u8(g["in_rand"], w), g[f"out_lee_rand_{w}"])
+    # windows where a fused multiply-add anywhere in the chain would change the result by one
+    np.testing.assert_array_equal(O.lee_filter_u8(g["in_lee_rounding"], 3), g["out_lee_rounding_3"])
 
 
 def test_denoise_stats_match_real_server(golden):
