@@ -112,6 +112,20 @@ __host__ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+// Source row y of a block of h rows whose neighbours' rows may be supplied: `top` = the r rows above it (row -r first),
+// `bot` = the r rows below it.  A side without halo rows is an image border: REFLECT_101 there -- which, for a block
+// shorter than the radius, reaches past the block's far end into the OTHER side's halo rows.
+__device__ __forceinline__ const uint8_t* halo_row(const uint8_t* simg, const uint8_t* top, const uint8_t* bot,
+                                                   int y, int h, int r, int64_t s_row)
+{
+    if ((unsigned)y < (unsigned)h) return simg + (int64_t)y * s_row;
+    if (y < 0 && !top) y = -y;
+    else if (y >= h && !bot) y = 2 * (h - 1) - y;
+    if (y < 0 && top) return top + (int64_t)(r + y) * s_row;
+    if (y >= h && bot) return bot + (int64_t)(y - h) * s_row;
+    return simg + (int64_t)reflect101(y, h) * s_row;
+}
+
 // XCD-aware work-item remap (guide T1, bijective form): blocks b and b+8 share an XCD (and its L2), so
 // give each of the 8 residue classes a CONTIGUOUS range of work items.  Speed only, never correctness.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks)

@@ -44,9 +44,7 @@ struct ConvGeom {
 // Source row `y` of the image (y may lie outside [0,h)): halo row if provided, else REFLECT_101.
 __device__ __forceinline__ const uint8_t* row_ptr(const ConvGeom& g, const uint8_t* simg, int y, int r)
 {
-    if (y < 0 && g.top) return g.top + (int64_t)(r + y) * g.s_row;
-    if (y >= g.h && g.bot) return g.bot + (int64_t)(y - g.h) * g.s_row;
-    return simg + (int64_t)reflect101(y, g.h) * g.s_row;
+    return halo_row(simg, g.top, g.bot, y, g.h, r, g.s_row);
 }
 
 __device__ __forceinline__ ss2 pk_max(ss2 a, ss2 b) { return __builtin_elementwise_max(a, b); }

@@ -136,7 +136,6 @@ __global__ __launch_bounds__(64) void median_hist_kernel(const uint8_t* __restri
         int res = find_rank(h01, h23, need, lane);
         auto column = [&](int c) { c = c < nc ? c : nc - 1; return s_hist[c * 64 + ((lane + c) & 63)]; };
         uint32_t d_new = column(1 + 2 * r), d_old = column(0);
-#pragma unroll 2
         for (int i = 1; i < nout; ++i) {
             const uint32_t d_new2 = column(i + 1 + 2 * r), d_old2 = column(i);   // next step's, in flight during the search
             h01 = h01 + bins_lo(d_new) - bins_lo(d_old);

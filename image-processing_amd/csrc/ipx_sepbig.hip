@@ -38,9 +38,7 @@ template <int RMAX> struct TapsPad { uint32_t k[2 * RMAX + 1]; };   // centred, 
 
 __device__ __forceinline__ const uint8_t* src_row(const HGeom& g, const uint8_t* simg, int y)
 {
-    if (y < 0 && g.top) return g.top + (int64_t)(g.r + y) * g.s_row;
-    if (y >= g.h && g.bot) return g.bot + (int64_t)(y - g.h) * g.s_row;
-    return simg + (int64_t)reflect101(y, g.h) * g.s_row;
+    return halo_row(simg, g.top, g.bot, y, g.h, g.r, g.s_row);
 }
 
 // u16 index, inside a scratch row, of the row-pass result for byte b (field order within each 16-byte group)

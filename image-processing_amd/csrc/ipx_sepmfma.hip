@@ -53,9 +53,7 @@ struct MTaps { uint8_t kx[32]; uint8_t ky[32]; };
 
 __device__ __forceinline__ const uint8_t* src_row(const MGeom& g, const uint8_t* simg, int y)
 {
-    if (y < 0 && g.top) return g.top + (int64_t)(g.r + y) * g.s_row;
-    if (y >= g.h && g.bot) return g.bot + (int64_t)(y - g.h) * g.s_row;
-    return simg + (int64_t)reflect101(y, g.h) * g.s_row;
+    return halo_row(simg, g.top, g.bot, y, g.h, g.r, g.s_row);
 }
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding GLOBAL loads

@@ -21,7 +21,8 @@ from ipx import ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=90)
 ap.add_argument("--seed", type=int, default=0)
-ap.add_argument("--ops", default="gray,lut,eq,grayeq,sharpen,box3,sobel,gauss,gauss,lee,median,morph")
+ap.add_argument("--ops", default="gray,lut,eq,grayeq,sharpen,box3,sobel,gauss,gauss,lee,median,morph,halo,stats")
+ap.add_argument("--big", action="store_true", help="images of up to ~3 MP and 3000 rows (slower oracle, fewer cases)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 dev = torch.device("cuda:0")
@@ -30,6 +31,10 @@ EDGE_W = [1, 2, 5, 15, 16, 17, 31, 33, 63, 64, 65, 127, 128, 129, 341, 342, 343,
 
 
 def rand_shape(max_px=400_000):
+    if a.big:
+        w = int(rng.choice(EDGE_W[8:])) if rng.random() < 0.3 else int(rng.integers(100, 4200))
+        h = int(rng.integers(1, max(2, min(3000, 3_000_000 // w))))
+        return h, w
     w = int(rng.choice(EDGE_W)) if rng.random() < 0.5 else int(rng.integers(1, 2200))
     h = int(rng.integers(1, max(2, min(300, max_px // w))))
     return h, w
@@ -117,6 +122,42 @@ while time.time() < t_end:
         k = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 21, 31]))
         t, img = make(n, h, w, 1, strided)
         fails += check(f"median{k}", ops.median_blur(t, k), per_image(lambda x: O.median_blur_u8(x, k), img), (n, h, w, strided))
+    elif op == "halo":
+        # a row block [y0, y1) of a taller image with r halo rows from its neighbours == the whole-image result cropped
+        c = int(rng.choice([1, 3]))
+        which = str(rng.choice(["sharpen", "box3", "sobel", "gauss"]))
+        k = int(rng.choice([3, 5, 7, 9, 15, 31])) if which == "gauss" else 3
+        r = k // 2
+        h = max(h, 3 * r + 3)
+        t, img = make(1, h, w, c, False)
+        y0 = 0 if rng.random() < 0.3 else int(rng.integers(r, h - r - 1))
+        lo = y0 + 1                                          # blocks shorter than r are legal next to an image border:
+        if lo >= h - r + 1 and rng.random() < 0.7:           # the reflection then reaches into the other side's halo
+            y1 = h
+        elif lo >= h - r + 1:
+            continue
+        else:
+            y1 = h if rng.random() < 0.3 else int(rng.integers(lo, h - r + 1))
+        if (y0 > 0 and y1 < h and y1 - y0 < r) or y1 <= y0:    # between two neighbours a block must hold r rows (RowPartition)
+            continue
+        local = t[0, y0:y1]
+        top = t[0, y0 - r:y0] if y0 > 0 else None
+        bot = t[0, y1:y1 + r] if y1 < h else None
+        if which == "gauss":
+            got = ops.gaussian_blur(local, k, top_halo=top, bottom_halo=bot)
+            want = per_image(lambda x: O.gaussian_blur_u8(x, k), img)[0, y0:y1]
+        else:
+            fn = {"sharpen": (ops.laplacian_sharpen, O.laplacian_sharpen_u8), "box3": (ops.box3, O.box3_u8), "sobel": (ops.sobel, O.sobel_u8)}[which]
+            got = fn[0](local, top_halo=top, bottom_halo=bot)
+            want = per_image(fn[1], img)[0, y0:y1]
+        fails += check(f"halo.{which}{k}", got, want, (h, w, c, y0, y1))
+    elif op == "stats":
+        t, img = make(1, h, w, 1, strided)
+        got = ops.denoise_stats(t[0, :, :, 0] if not strided else t[0, :, :, 0].contiguous())
+        want = O.denoise_stats(img[0, :, :, 0])
+        if any(got[k2] != want[k2] for k2 in want):
+            print(f"MISMATCH stats {(h, w)}: {got} vs {want}", flush=True)
+            fails += 1
     else:
         h, w = min(h, 150), min(w, 700)
         m = int(rng.choice([1, 3, 5, 7, 9, 15, 31]))

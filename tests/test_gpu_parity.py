@@ -249,6 +249,27 @@ def test_halo_rows_equal_whole_image(dev, cn):
             np.testing.assert_array_equal(host(got), whole[y0:y1], err_msg=f"{name} rows {y0}:{y1}")
 
 
+@pytest.mark.parametrize("cn", [1, 3])
+def test_halo_rows_block_shorter_than_radius_at_image_border(dev, cn):
+    """A first / last row block of fewer rows than the radius: REFLECT_101 at the image border reaches past the block
+    into the neighbour's halo rows (row -1 of a 1-row first block is global row 1 = the first bottom halo row)."""
+    img = rnd((40, 300) + ((cn,) if cn > 1 else ()), 15)
+    t = dev_t(img, dev)
+    for name, ref, r in [("sobel", O.sobel_u8, 1), ("box3", O.box3_u8, 1), ("laplacian_sharpen", O.laplacian_sharpen_u8, 1),
+                         ("g5", lambda a: O.gaussian_blur_u8(a, 5), 2), ("g7", lambda a: O.gaussian_blur_u8(a, 7), 3),
+                         ("g15", lambda a: O.gaussian_blur_u8(a, 15), 7), ("g31", lambda a: O.gaussian_blur_u8(a, 31), 15)]:
+        whole = ref(img)
+        for rows in {1, max(1, r - 1), r}:
+            for (y0, y1) in ((0, rows), (40 - rows, 40)):
+                top = t[y0 - r:y0] if y0 > 0 else None
+                bot = t[y1:y1 + r] if y1 < 40 else None
+                if name.startswith("g"):
+                    got = ops.gaussian_blur(t[y0:y1], int(name[1:]), top_halo=top, bottom_halo=bot)
+                else:
+                    got = getattr(ops, name)(t[y0:y1], top_halo=top, bottom_halo=bot)
+                np.testing.assert_array_equal(host(got), whole[y0:y1], err_msg=f"{name} rows {y0}:{y1}")
+
+
 def test_golden_server_cases_on_device(dev, golden):
     """The real server.py outputs (tests/golden) reproduced by host-built table + device apply."""
     g, meta = golden
