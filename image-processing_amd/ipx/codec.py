@@ -8,7 +8,12 @@ Encoded PNG bytes need not match the reference's; decoded pixels must.
 from __future__ import annotations
 
 import base64
+import concurrent.futures
 import io
+import os
+import struct
+import threading
+import zlib
 
 import numpy as np
 from PIL import Image
@@ -53,14 +58,62 @@ def decode_color(img_bytes: bytes):
     return np.ascontiguousarray(a[:, :, :3])
 
 
+_POOL = None
+_POOL_LOCK = threading.Lock()
+_BAND_BYTES = 1 << 20            # filtered bytes per independently deflated band
+
+
+def _pool():
+    global _POOL
+    with _POOL_LOCK:
+        if _POOL is None:
+            n = int(os.environ.get("IPX_CODEC_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            _POOL = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, n), thread_name_prefix="ipx-png")
+        return _POOL
+
+
+def _chunk(tag: bytes, data: bytes) -> bytes:
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(data, zlib.crc32(tag)) & 0xFFFFFFFF)
+
+
+def encode_png(img: np.ndarray, level: int = 1) -> bytes:
+    """PNG writer for H x W (gray) or H x W x 3 (RGB order) uint8 whose deflate work runs on all host cores: the
+    'Up'-filtered scan lines are cut into bands, every band is deflated on its own (zlib releases the GIL) and ends on a
+    byte boundary (Z_SYNC_FLUSH), and the bands are concatenated into ONE zlib stream, as pigz does.  PNG encoding is
+    the largest part of a request (scripts/e2ebench.py); the decoded pixels are what the contract fixes, not these bytes."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape[:2]
+    rows = img.reshape(h, -1)
+    raw = np.empty((h, rows.shape[1] + 1), np.uint8)
+    raw[:, 0] = 2                                                      # filter type 2 (Up) on every row
+    raw[0, 1:] = rows[0]
+    np.subtract(rows[1:], rows[:-1], out=raw[1:, 1:])                  # uint8 arithmetic wraps, as the filter does
+    flat = raw.reshape(-1)
+    per = max(1, _BAND_BYTES // raw.shape[1]) * raw.shape[1]
+    bands = [flat[o:o + per] for o in range(0, flat.size, per)]
+
+    def deflate(i):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        return co.compress(bands[i]) + co.flush(zlib.Z_FINISH if i == len(bands) - 1 else zlib.Z_SYNC_FLUSH)
+
+    parts = [deflate(0)] if len(bands) == 1 else list(_pool().map(deflate, range(len(bands))))
+    stream = b"\x78\x01" + b"".join(parts) + struct.pack(">I", zlib.adler32(flat) & 0xFFFFFFFF)
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, 0 if img.ndim == 2 else 2, 0, 0, 0)
+    return b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", stream) + _chunk(b"IEND", b"")
+
+
 def to_data_url_png(img: np.ndarray) -> str:
     """server.py:533-538.  `img` is H x W gray or H x W x 3 BGR uint8."""
     img = np.asarray(img)
+    if img.ndim == 3 and img.shape[2] == 1:
+        img = img[:, :, 0]
     if img.ndim == 3:
-        img = img[:, :, ::-1]                                          # BGR -> RGB for Pillow
-    buf = io.BytesIO()
-    Image.fromarray(np.ascontiguousarray(img)).save(buf, format="PNG", compress_level=1)
-    return "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode("ascii")
+        img = img[:, :, ::-1]                                          # BGR -> RGB, PNG's order
+    if img.dtype != np.uint8 or img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] != 3) or img.size == 0:
+        buf = io.BytesIO()                                             # anything unusual: Pillow's writer
+        Image.fromarray(np.ascontiguousarray(img)).save(buf, format="PNG", compress_level=1)
+        return "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode("ascii")
+    return "data:image/png;base64," + base64.b64encode(encode_png(img)).decode("ascii")
 
 
 def from_data_url_png(url: str) -> np.ndarray:

@@ -1,0 +1,70 @@
+"""End-to-end request timing on the GPU box: POST /api/process through Flask's test
+client with the HIP backend, next to the codec's share (PNG decode + PNG encode + base64, CPU by design).  Records, not
+bench lines.  usage: python scripts/e2ebench.py [--reps 5]"""
+import argparse
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "image-processing_amd"))
+import numpy as np
+from PIL import Image
+
+import ipx.app as app_mod
+import ipx.codec as codec
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+client = app_mod.create_app().test_client()
+rng = np.random.default_rng(0)
+
+
+def png(arr):
+    buf = io.BytesIO()
+    Image.fromarray(arr).save(buf, format="PNG", compress_level=1)
+    return buf.getvalue()
+
+
+def smooth(h, w, c):
+    """a photograph-like image (smooth gradients + mild noise): PNG cost depends on content"""
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 128 + 60 * np.sin(xx / 97.0) * np.cos(yy / 131.0)
+    img = np.stack([base + 20 * np.sin((xx + 50 * k) / 41.0) for k in range(c)], -1) + rng.normal(0, 4, (h, w, c))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    return img[:, :, 0] if c == 1 else img
+
+
+out = {}
+for (h, w) in ((512, 512), (2160, 3840)):
+    for mode, c, form in (("gamma", 1, {"gamma": "0.6"}), ("histogram_eq", 3, {}), ("sharpening", 3, {}),
+                          ("denoise_manual", 1, {"method": "lee", "kernel": "5"}), ("median", 1, {"k": "5"})):
+        data = png(smooth(h, w, c))
+        def once():
+            t0 = time.perf_counter()
+            r = client.post("/api/process", data={"mode": mode, "file": (io.BytesIO(data), "x.png"), **form},
+                            content_type="multipart/form-data")
+            assert r.status_code == 200, r.get_json()
+            return time.perf_counter() - t0, r.get_json()
+        once()
+        ts = []
+        for _ in range(a.reps):
+            t, js = once()
+            ts.append(t)
+        t0 = time.perf_counter()
+        dec = codec.decode_unchanged(data)
+        t_dec = time.perf_counter() - t0
+        res = codec.from_data_url_png(js["dataURL"])
+        t0 = time.perf_counter()
+        codec.to_data_url_png(res)
+        t_enc = time.perf_counter() - t0
+        mp = h * w / 1e6
+        rec = {"ms_total": round(1e3 * float(np.median(ts)), 2), "ms_png_decode": round(1e3 * t_dec, 2),
+               "ms_png_encode_b64": round(1e3 * t_enc, 2), "request_MP_per_s": round(mp / float(np.median(ts)), 1)}
+        rec["ms_rest (upload, kernels, download, Flask)"] = round(rec["ms_total"] - rec["ms_png_decode"] - rec["ms_png_encode_b64"], 2)
+        out[f"{mode}_{w}x{h}"] = rec
+        print(mode, f"{w}x{h}", rec, flush=True)
+print(json.dumps(out))

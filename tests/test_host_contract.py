@@ -196,3 +196,35 @@ def test_batch_sharder_order_and_round_robin():
     assert list(shard_range(7, 1, 3)) == [1, 4] and list(shard_range(2, 3, 4)) == []
     with pytest.raises(RuntimeError, match="failed"):
         sh.map(imgs, lambda ops, t: ops.nonexistent(t))
+
+
+def test_png_writer_round_trips_and_is_one_valid_stream():
+    """ipx.codec.encode_png (band-parallel deflate): any decoder must read back the same pixels -- Pillow here, and
+    zlib on the concatenated IDAT stream (checks the joined bands and the Adler-32 trailer)."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:700, 0:900]
+    smooth = (128 + 90 * np.sin(xx / 37.0) * np.cos(yy / 53.0)).astype(np.uint8)
+    cases = [rng.integers(0, 256, (1, 1), dtype=np.uint8), rng.integers(0, 256, (3, 5, 3), dtype=np.uint8),
+             rng.integers(0, 256, (1200, 1100), dtype=np.uint8),                  # > 1 MiB: two bands, incompressible
+             smooth, np.stack([smooth, smooth.T[:700, :700].repeat(2, 1)[:, :900], 255 - smooth], -1),
+             np.zeros((2000, 1500), np.uint8)]                                      # many bands of all-zero rows
+    for img in cases:
+        data = codec.encode_png(img)
+        back = np.array(Image.open(io.BytesIO(data)))
+        np.testing.assert_array_equal(back, img)
+        pos, idat = 8, b""
+        while pos < len(data):
+            n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+            body = data[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xFFFFFFFF
+            if tag == b"IDAT":
+                idat += body
+            pos += 12 + n
+        raw = zlib.decompress(idat)                                                 # raises on a bad stream / checksum
+        assert len(raw) == img.shape[0] * (img[0].size + 1)
+    bgr = rng.integers(0, 256, (40, 30, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(codec.from_data_url_png(codec.to_data_url_png(bgr)), bgr)
+    g1 = rng.integers(0, 256, (40, 30, 1), dtype=np.uint8)
+    np.testing.assert_array_equal(codec.from_data_url_png(codec.to_data_url_png(g1)), g1[:, :, 0])
