@@ -28,9 +28,10 @@ def _open(img_bytes: bytes) -> Image.Image:
         raise RuntimeError("Cannot decode image to grayscale 8-bit. " + str(e))
 
 
-def decode_unchanged(img_bytes: bytes) -> np.ndarray:
+def decode_unchanged(img_bytes: bytes, order: str = "bgr") -> np.ndarray:
     """cv2.imdecode(arr, IMREAD_UNCHANGED) equivalent (server.py:499-501): 2-D gray (uint8/uint16) or
-    H x W x {3,4} BGR(A) uint8."""
+    H x W x {3,4} BGR(A) uint8.  order="rgb" skips the channel reversal (a 25 MB host copy at 4K): the caller then
+    reverses on the GPU, or not at all for per-channel filters."""
     im = _open(img_bytes)
     if im.mode in ("L",):
         return np.array(im, dtype=np.uint8)
@@ -40,22 +41,22 @@ def decode_unchanged(img_bytes: bytes) -> np.ndarray:
         return (np.array(im, dtype=np.uint8) * 255).astype(np.uint8)
     if im.mode in ("RGBA", "LA", "PA") or (im.mode == "P" and "transparency" in im.info):
         a = np.array(im.convert("RGBA"), dtype=np.uint8)
-        return np.ascontiguousarray(a[:, :, [2, 1, 0, 3]])            # RGBA -> BGRA
+        return a if order == "rgb" else np.ascontiguousarray(a[:, :, [2, 1, 0, 3]])   # RGBA -> BGRA
     a = np.array(im.convert("RGB"), dtype=np.uint8)
-    return np.ascontiguousarray(a[:, :, ::-1])                        # RGB -> BGR
+    return a if order == "rgb" else np.ascontiguousarray(a[:, :, ::-1])               # RGB -> BGR
 
 
-def decode_color(img_bytes: bytes):
+def decode_color(img_bytes: bytes, order: str = "bgr"):
     """cv2.imdecode(arr, IMREAD_COLOR) equivalent (server.py:252): always H x W x 3 BGR uint8, or None."""
     try:
-        a = decode_unchanged(img_bytes)
+        a = decode_unchanged(img_bytes, order)
     except RuntimeError:
         return None
     if a.dtype == np.uint16:
         a = (a >> 8).astype(np.uint8)
     if a.ndim == 2:
         return np.ascontiguousarray(np.repeat(a[:, :, None], 3, axis=2))
-    return np.ascontiguousarray(a[:, :, :3])
+    return a if a.shape[2] == 3 else np.ascontiguousarray(a[:, :, :3])
 
 
 _POOL = None
@@ -102,12 +103,12 @@ def encode_png(img: np.ndarray, level: int = 1) -> bytes:
     return b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", stream) + _chunk(b"IEND", b"")
 
 
-def to_data_url_png(img: np.ndarray) -> str:
-    """server.py:533-538.  `img` is H x W gray or H x W x 3 BGR uint8."""
+def to_data_url_png(img: np.ndarray, order: str = "bgr") -> str:
+    """server.py:533-538.  `img` is H x W gray or H x W x 3 uint8, BGR unless order="rgb"."""
     img = np.asarray(img)
     if img.ndim == 3 and img.shape[2] == 1:
         img = img[:, :, 0]
-    if img.ndim == 3:
+    if img.ndim == 3 and order != "rgb":
         img = img[:, :, ::-1]                                          # BGR -> RGB, PNG's order
     if img.dtype != np.uint8 or img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] != 3) or img.size == 0:
         buf = io.BytesIO()                                             # anything unusual: Pillow's writer

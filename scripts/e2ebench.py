@@ -55,11 +55,11 @@ for (h, w) in ((512, 512), (2160, 3840)):
             t, js = once()
             ts.append(t)
         t0 = time.perf_counter()
-        dec = codec.decode_unchanged(data)
+        dec = codec.decode_unchanged(data, "rgb")
         t_dec = time.perf_counter() - t0
         res = codec.from_data_url_png(js["dataURL"])
         t0 = time.perf_counter()
-        codec.to_data_url_png(res)
+        codec.to_data_url_png(res, "rgb")
         t_enc = time.perf_counter() - t0
         mp = h * w / 1e6
         rec = {"ms_total": round(1e3 * float(np.median(ts)), 2), "ms_png_decode": round(1e3 * t_dec, 2),
