@@ -68,7 +68,11 @@ def to_bgr(t):
 
 def ensure_gray_uint8(backend, img_bytes: bytes) -> np.ndarray:
     """server.py:492-531: decode, drop alpha, BGR->gray (GPU), 16-bit >> 8."""
-    img = codec.decode_unchanged(img_bytes, "rgb")
+    return gray_from_decoded(backend, codec.decode_unchanged(img_bytes, "rgb"))
+
+
+def gray_from_decoded(backend, img: np.ndarray) -> np.ndarray:
+    """The part of ensure_gray_uint8 after the decode (`img` in RGB(A) order as decode_unchanged(..., "rgb") returns it)."""
     if img.ndim == 3:
         img = backend.run(lambda ops, t: ops.bgr2gray(to_bgr(t)), img)  # 3 or 4 channels; alpha dropped
     if img.dtype == np.uint16:
@@ -248,13 +252,13 @@ def create_app(backend=None) -> Flask:
         is_log = mode in ("log", "logarithmic", "logrithmic")       # server.py:383-388
         if is_log:
             c_val = float(form.get("c", "2.0"))
-            gray = ensure_gray_uint8(b, data) if img.ndim == 3 or img.dtype != np.uint8 else img
+            gray = gray_from_decoded(b, img)                          # (the reference decodes a second time here)
             hist = b.run(lambda ops, t: ops.hist(t), gray)           # s.max() needs the levels present
             out = b.run(lambda ops, t: ops.apply_lut(t, luts.log(c_val, hist)), gray)
         elif lut is not None and img.ndim == 3:
             out = b.run(lambda ops, t: ops.bgr2gray_lut(to_bgr(t), lut), img)   # gray + table in one pass
         else:
-            gray = ensure_gray_uint8(b, data) if img.ndim == 3 or img.dtype != np.uint8 else img
+            gray = gray_from_decoded(b, img)
             out = gray if lut is None else b.run(lambda ops, t: ops.apply_lut(t, lut), gray)
         return {"dataURL": codec.to_data_url_png(out), "message": "ok", "params": params}, 200
 
