@@ -112,6 +112,12 @@ while time.time() < t_end:
         k = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 17, 21, 25, 31]))
         t, img = make(n, h, w, c, strided)
         fails += check(f"gauss{k}", ops.gaussian_blur(t, k), per_image(lambda x: O.gaussian_blur_u8(x, k), img), (n, h, w, c, strided))
+    elif op == "gaussbig":                                   # the generic two-pass path (k > 31)
+        c = int(rng.choice([1, 3]))
+        k = int(rng.choice([33, 45, 63, 101, 255]))
+        h, w = min(h, 200), min(w, 600)
+        t, img = make(n, h, w, c, strided)
+        fails += check(f"gauss{k}", ops.gaussian_blur(t, k), per_image(lambda x: O.gaussian_blur_u8(x, k), img), (n, h, w, c, strided))
     elif op == "lee":
         h, w = min(h, 120), min(w, 300)
         win = int(rng.choice([1, 3, 5, 7, 9, 15, 31]))
