@@ -64,7 +64,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
 __device__ __forceinline__ us2 bins_lo(uint32_t d) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, d, 0x0c010c00u)); }
 __device__ __forceinline__ us2 bins_hi(uint32_t d) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, d, 0x0c030c02u)); }
 
-__device__ __forceinline__ int find_rank(us2 h01, us2 h23, int need, int lane)
+__device__ __forceinline__ int find_rank(us2 h01, us2 h23, int need)
 {
     const us2 ones = {1, 1};
     const int t = (int)__builtin_amdgcn_udot2(h01, ones, __builtin_amdgcn_udot2(h23, ones, 0u, false), false);
@@ -75,7 +75,6 @@ __device__ __forceinline__ int find_rank(us2 h01, us2 h23, int need, int lane)
     const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint32_t, h01), L);
     const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint32_t, h23), L);
     const int c0 = below + (int)(a & 0xffffu), c1 = c0 + (int)(a >> 16), c2 = c1 + (int)(b & 0xffffu);
-    (void)lane;
     return 4 * L + (c0 < need) + (c1 < need) + (c2 < need);
 }
 
@@ -133,14 +132,14 @@ __global__ __launch_bounds__(64) void median_hist_kernel(const uint8_t* __restri
             h01 += bins_lo(d);
             h23 += bins_hi(d);
         }
-        int res = find_rank(h01, h23, need, lane);
+        int res = find_rank(h01, h23, need);
         auto column = [&](int c) { c = c < nc ? c : nc - 1; return s_hist[c * 64 + ((lane + c) & 63)]; };
         uint32_t d_new = column(1 + 2 * r), d_old = column(0);
         for (int i = 1; i < nout; ++i) {
             const uint32_t d_new2 = column(i + 1 + 2 * r), d_old2 = column(i);   // next step's, in flight during the search
             h01 = h01 + bins_lo(d_new) - bins_lo(d_old);
             h23 = h23 + bins_hi(d_new) - bins_hi(d_old);
-            const int m = find_rank(h01, h23, need, lane);
+            const int m = find_rank(h01, h23, need);
             res = lane == i ? m : res;
             d_new = d_new2;
             d_old = d_old2;
@@ -265,22 +264,18 @@ __global__ __launch_bounds__(kTileW * kTileH) void morph_kernel(const uint8_t* _
     const int lx = tid % kTileW, ly = tid / kTileW;
     const int x = tx0 + lx, y = ty0 + ly;
     if (x >= g.w || y >= g.h) return;
-    const int KW = 2 * g.rx + 1, KH = 2 * g.ry + 1;
+    const int KH = 2 * g.ry + 1;
     const uint8_t* base = s_tile + ly * kPitch + lx;
     uint32_t acc = DILATE ? 0u : 255u;
-    bool any = false;
     for (int wy = 0; wy < KH; ++wy) {
-        const uint32_t bits = se.bits[wy];                 // block-uniform
+        uint32_t bits = se.bits[wy];                       // block-uniform: walk the set positions only
         const uint8_t* rp = base + wy * kPitch;
-        for (int wx = 0; wx < KW; ++wx) {
-            if ((bits >> wx) & 1u) {
-                const uint32_t v = rp[wx];
-                acc = DILATE ? (v > acc ? v : acc) : (v < acc ? v : acc);
-                any = true;
-            }
+        while (bits) {
+            const uint32_t v = rp[__builtin_ctz(bits)];
+            bits &= bits - 1;
+            acc = DILATE ? (v > acc ? v : acc) : (v < acc ? v : acc);
         }
     }
-    (void)any;
     dst[(int64_t)img * g.d_img + (int64_t)y * g.d_row + x] = (uint8_t)acc;
 }
 

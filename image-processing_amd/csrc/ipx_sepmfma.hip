@@ -194,10 +194,9 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
     // per-lane LDS addresses (tile independent)
     uint8_t* const st_src = s_src + lrow * PS + 16 * lch;                       // source staging: + 32 i PS
     const uint8_t* const a_h = s_src + m * PS + 16 * gq + 16 * wave;            // row pass A: + 16 mt PS + 64 q
-    constexpr int swz = 0;
-    uint8_t* const w_hi = s_ht0 + (16 * wave + m) * kPitchH + 4 * gq;           // row pass result: + 16 (mt ^ swz)
+    uint8_t* const w_hi = s_ht0 + (16 * wave + m) * kPitchH + 4 * gq;           // row pass result: + 16 mt
     uint8_t* const w_lo = s_ht1 + (16 * wave + m) * kPitchH + 4 * gq;
-    const uint8_t* const a_vhi = s_ht0 + (16 * wave + m) * kPitchH;             // column pass A: + 16 ((nt + gq) ^ swz)
+    const uint8_t* const a_vhi = s_ht0 + (16 * wave + m) * kPitchH;             // column pass A: + 16 (nt + gq)
     const uint8_t* const a_vlo = s_ht1 + (16 * wave + m) * kPitchH;
     uint8_t* const s_out = s_src;
     uint8_t* const w_out = s_out + m * kPitchO + 16 * wave + 4 * gq;            // + 16 nt kPitchO
@@ -237,8 +236,8 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
         const uint32_t h0 = (uint32_t)acc[0], h1 = (uint32_t)acc[1], h2 = (uint32_t)acc[2], h3 = (uint32_t)acc[3];
         const uint32_t hi = __builtin_amdgcn_perm(h1, h0, 0x0c0c0501u) | __builtin_amdgcn_perm(h3, h2, 0x05010c0cu);
         const uint32_t lo = (__builtin_amdgcn_perm(h1, h0, 0x0c0c0400u) | __builtin_amdgcn_perm(h3, h2, 0x04000c0cu)) ^ 0x80808080u;
-        *reinterpret_cast<uint32_t*>(w_hi + 16 * (mt ^ swz)) = hi;
-        *reinterpret_cast<uint32_t*>(w_lo + 16 * (mt ^ swz)) = lo;
+        *reinterpret_cast<uint32_t*>(w_hi + 16 * mt) = hi;
+        *reinterpret_cast<uint32_t*>(w_lo + 16 * mt) = lo;
     }
     lds_barrier();
 
@@ -249,7 +248,7 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
     for (int nt = 0; nt < TY / 16; ++nt) {
         constexpr int c0 = 32768 * 256 + 32768 + 32768;          // rounding and the two +2^15 offsets, via the accumulator
         const v4i z = {0, 0, 0, 0}, zc = {c0, c0, c0, c0};
-        const int vo = 16 * ((nt + gq) ^ swz);
+        const int vo = 16 * (nt + gq);
         const v4i dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_vhi + vo), bv, z, 0, 0, 0);
         const v4i dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_vlo + vo), bv, zc, 0, 0, 0);
         uint32_t o[4];
