@@ -436,3 +436,46 @@ def test_full_size_properties(dev):
     sb = ops.sobel(gray)
     band = gray[0, 2060:2160, :, 0].cpu().numpy()
     np.testing.assert_array_equal(sb[0, 2061:2160, :, 0].cpu().numpy(), O.sobel_u8(band)[1:])
+
+
+def test_full_size_rank_and_lee_filters(dev):
+    """Median, morphology and the Lee filter on a 4K frame: random interior crops and the image corners against the
+    oracle (crop + margin), plus order properties that need no oracle (erode <= src <= dilate, open <= src <= close,
+    median of a constant / of a two-level image stays inside the levels)."""
+    h, w = 2160, 3840
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[500:900, 1000:2600] = (img[500:900, 1000:2600] // 128) * 255          # a two-level region: many equal values
+    t = dev_t(img, dev)
+
+    def crops(r, size=80):
+        cs = [(int(rng.integers(r, h - size - r)), int(rng.integers(r, w - size - r))) for _ in range(4)]
+        cs += [(600, 1500), (0, 0), (0, w - size), (h - size, 0), (h - size, w - size), (2100, 2000)]
+        return cs, size
+
+    def check(got, fn, r, replicate):
+        cs, size = crops(r)
+        for (y, x) in cs:
+            y0, y1, x0, x1 = max(0, y - r), min(h, y + size + r), max(0, x - r), min(w, x + size + r)
+            at_border = y0 == 0 or x0 == 0 or y1 == h or x1 == w
+            ref = fn(img[y0:y1, x0:x1])                     # the crop's own border handling is only right AT the image border
+            sub = ref[y - y0:y - y0 + size, x - x0:x - x0 + size]
+            if at_border and not replicate:
+                continue
+            np.testing.assert_array_equal(got[y:y + size, x:x + size], sub, err_msg=f"crop {y},{x} r={r}")
+
+    for k in (3, 5, 9, 11, 31):
+        check(host(ops.median_blur(t, k)), lambda a: O.median_blur_u8(a, k), k // 2, True)
+    for wnd in (5, 31):                                     # Lee copies the border band: only interior crops are comparable
+        got = host(ops.lee_filter(t, wnd))
+        check(got, lambda a: O.lee_filter_u8(a, wnd), wnd // 2 + wnd // 2, False)
+        np.testing.assert_array_equal(got[:wnd // 2], img[:wnd // 2])
+    se = ops.ellipse_se(7)
+    er, di = ops.erode(t, se), ops.dilate(t, se)
+    assert bool((er <= t).all()) and bool((t <= di).all())
+    op, cl = ops.morph_open(t, se), ops.morph_close(t, se)
+    assert bool((op <= t).all()) and bool((t <= cl).all())
+    check(host(op), lambda a: O.morph_open_u8(a, se), 6, True)
+    two = dev_t(img[500:900, 1000:2600], dev)
+    m = ops.median_blur(two, 7)
+    assert set(torch.unique(m).tolist()) <= {0, 255}
