@@ -229,19 +229,15 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void conv3_kernel(const uin
 #pragma unroll
     for (int j = 0; j < U; ++j) load_win<C, 1>(nx[j], row(2 + j), b0);
     for (int i = 0; i < nrows; i += U) {
-        W1 nn[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) load_win<C, 1>(nn[j], row(i + U + 2 + j), b0);   // next step's rows
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             typename Op::Feat fc;
             Op::feat(fc, nx[j]);
+            load_win<C, 1>(nx[j], row(i + U + 2 + j), b0);   // the slot is free: refill it with the row U steps further on
             if (i + j < nrows) st16_nt(dimg + (int64_t)(ys + dir * (i + j)) * g.d_row + b0, Op::out(fa, fb, fc));
             fa = fb;
             fb = fc;
         }
-#pragma unroll
-        for (int j = 0; j < U; ++j) nx[j] = nn[j];
     }
 }
 
