@@ -10,7 +10,8 @@ in HBM.  One step = for every image of the batch:
 value = (ranks x batch x 8.2944 MP) / step time: pixels pushed through the whole pipeline per second.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the 5x5 Gaussian) by its algorithmic
-bytes; `kernels` lists every op of the step the same way; `cpu_baseline` times the C oracle (a port, not the
+bytes and its duration between two HIP events in every timed step; `kernels` lists every op of the step the same way
+(the other two ops from K instrumented steps run after the timed region); `cpu_baseline` times the C oracle (a port, not the
 reference: OpenCV is absent) on a bounded sample of the same workload on this box's host cores.
 """
 from __future__ import annotations
@@ -105,22 +106,31 @@ def main():
     order = ORDERS[args.order]
     STEP_OPS = [STEP_OPS[i] for i in order]
 
-    def step(ev=None):
-        """One pass of the pipeline over the resident batch; `ev` (optional) receives one HIP event per op boundary,
-        recorded on the stream the kernels are launched on (torch's current stream).  The three ops are independent
-        except that Sobel needs the gray image; --order only changes which runs first."""
+    DOMINANT = 0                                                  # index into the unordered op list: the 5x5 Gaussian
+
+    def step(ev=None, only=None):
+        """One pass of the pipeline over the resident batch; `ev` (optional) receives HIP events at op boundaries,
+        recorded on the stream the kernels are launched on (torch's current stream): around every op, or with `only`
+        around that op alone (ev[0], ev[1]).  An event between two kernels keeps them from overlapping at their edges
+        (measured: 4 events per step cost 2-3 % of the step, scripts/dev/evprobe.py), so the timed region carries only
+        the two around the dominant kernel.  The three ops are independent except that Sobel needs the gray image;
+        --order only changes which runs first."""
         res = {}
-        if ev is not None:
+        if ev is not None and only is None:
             ev[0].record()
         for j, i in enumerate(order):
+            if ev is not None and only == i:
+                ev[0].record()
             if i == 0:
                 res["g5"] = ops.gaussian_blur(bgr, 5)
             elif i == 1:
                 res["gray"], res["eq"] = ops.bgr2gray_equalize(bgr)   # cvtColor + equalizeHist, histogram taken while gray is written
             else:
                 res["sb"] = ops.sobel(res["gray"])
-            if ev is not None:
+            if ev is not None and only is None:
                 ev[j + 1].record()
+            if ev is not None and only == i:
+                ev[1].record()
         return res["g5"], res["sb"], res["eq"]
 
     def fence():
@@ -136,13 +146,18 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    dom_events = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(events[i])
+        step(dom_events[i], only=DOMINANT)
     fence()
     dt = time.perf_counter() - t0
+    # the same K steps once more, instrumented around every op (outside the timed region): the per-op table
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    for i in range(args.steps):
+        step(events[i])
+    torch.cuda.synchronize()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -172,11 +187,16 @@ def main():
                     "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4), "MPps": round(px / s / 1e6, 1),
                     "timing": how}
 
-        # per-op durations INSIDE the timed region: HIP events between the ops of every timed step
+        # the dominant kernel: HIP events around it in every TIMED step; the other ops of the step: events around every
+        # op in K more steps run right after the timed region
         kernels = {}
         for j, (name, kern, bpp) in enumerate(STEP_OPS):
-            s = sum(events[i][j].elapsed_time(events[i][j + 1]) for i in range(args.steps)) / args.steps * 1e-3
-            kernels[name] = row(kern, bpp, s, "HIP events around the op in every timed step (in-pipeline)")
+            if order[j] == DOMINANT:
+                s = sum(e[0].elapsed_time(e[1]) for e in dom_events) / args.steps * 1e-3
+                kernels[name] = row(kern, bpp, s, "HIP events around the op in every timed step (in-pipeline)")
+            else:
+                s = sum(events[i][j].elapsed_time(events[i][j + 1]) for i in range(args.steps)) / args.steps * 1e-3
+                kernels[name] = row(kern, bpp, s, "HIP events around every op in K instrumented steps after the timed region (in-pipeline)")
         if args.ops_table:
             gray = ops.bgr2gray(bgr)
             for name, kern, bpp, fn in [
