@@ -15,6 +15,8 @@
 // to ipx_sepbig.hip, a row-pass kernel + column-pass kernel around a Q8.8 scratch image).  Anything larger
 // (and k = 1) goes through the simple generic two-pass path at the bottom of this file.
 #include "ipx_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include "ipx_fields.h"
 #include <stdlib.h>
 #include <vector>
@@ -39,6 +41,7 @@ struct ConvGeom {
     unsigned border_total;             // n * h * nb
     const uint8_t* top;                // r halo rows above row 0 (row -r first), or null = reflect
     const uint8_t* bot;                // r halo rows below row h-1, or null = reflect
+    unsigned long long* trace;         // dev (IPX_CONV_TRACE): per wave start / end time stamps, else null
 };
 
 // Source row `y` of the image (y may lie outside [0,h)): halo row if provided, else REFLECT_101.
@@ -294,8 +297,10 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
                                                              ConvGeom g, Taps<K> t)
 {
     constexpr int R = K / 2, NP = (K + 1) / 2;
+    const unsigned trace_id = 2u * (blockIdx.x * (unsigned)g.wpb + (threadIdx.x >> 6));
     if (blockIdx.x >= g.main_blocks) {                       // ---- border bytes, one per thread
         unsigned img; int y, b;
+        if (g.trace && (threadIdx.x & 63u) == 0) g.trace[trace_id] = __builtin_amdgcn_s_memrealtime();
         if (!border_item(g, blockIdx.x - g.main_blocks, img, y, b)) return;
         const uint8_t* simg = src + (int64_t)img * g.s_img;
         const int px = b / C, ch = b - px * C;
@@ -312,6 +317,7 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
             acc += tap_y<K>(t, i) * hsum;
         }
         dst[(int64_t)img * g.d_img + (int64_t)y * g.d_row + b] = (uint8_t)(acc >> 16);
+        if (g.trace && (threadIdx.x & 63u) == 0) g.trace[trace_id + 1] = __builtin_amdgcn_s_memrealtime();
         return;
     }
     unsigned img; int y0, y1, lane0;
@@ -322,6 +328,8 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     typedef Win<C, R> WR;
+    const bool tracer = g.trace && (threadIdx.x & 63u) == (gl == 1 ? 1u : 0u);
+    if (tracer) g.trace[trace_id] = __builtin_amdgcn_s_memrealtime();
 
     const int nrows = y1 - y0;
     const int ys = y0;
@@ -376,6 +384,7 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
             }
         }
     }
+    if (tracer) g.trace[trace_id + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---- generic two-pass path (any odd K <= IPX_MAX_GAUSS_K) -----------------------------------------------
@@ -438,6 +447,7 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
     g.h = h; g.w = w; g.L = w * c;
     g.s_row = s_row; g.s_img = s_img; g.d_row = d_row; g.d_img = d_img;
     g.top = top; g.bot = bot;
+    g.trace = nullptr;
     const int hd4 = 4 * ((r * c + 3) / 4);
     // main-region lane i covers bytes [16 + 16 i, 32 + 16 i) and reads hd4 bytes on either side of them
     g.nlanes = g.L >= 32 + hd4 ? (g.L - 32 - hd4) / 16 + 1 : 0;
@@ -576,7 +586,23 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     if (sx != 256 || sy != 256) return ipx_fail(IPX_ERR_INVALID, "%s: taps must sum to 256 (got %u, %u)", fn, sx, sy);
     hipStream_t st = (hipStream_t)stream;
     if (k == 3) { launch_sep_small_c<3>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<3>"); return IPX_OK; }
-    if (k == 5) { launch_sep_small_c<5>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<5>"); return IPX_OK; }
+    if (k == 5) {
+        const char* tf = getenv("IPX_CONV_TRACE");                    // dev knob: dump per-wave start / end stamps (100 MHz)
+        if (tf) {
+            const size_t nw = (size_t)conv_grid(g) * g.wpb, bytes = 2 * nw * sizeof(unsigned long long);
+            IPX_HIP(hipMalloc((void**)&g.trace, bytes));
+            IPX_HIP(hipMemset(g.trace, 0, bytes));
+            launch_sep_small_c<5>(st, src, dst, g, c, kx_q8, ky_q8);
+            IPX_HIP(hipDeviceSynchronize());
+            unsigned long long* hst = (unsigned long long*)malloc(bytes);
+            IPX_HIP(hipMemcpy(hst, g.trace, bytes, hipMemcpyDeviceToHost));
+            if (FILE* f = fopen(tf, "wb")) { const unsigned long long hdr[2] = {(unsigned long long)g.main_blocks * g.wpb, 0}; fwrite(hdr, 1, sizeof(hdr), f); fwrite(hst, 1, bytes, f); fclose(f); }
+            free(hst);
+            IPX_HIP(hipFree(g.trace));
+            return IPX_OK;
+        }
+        launch_sep_small_c<5>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<5>"); return IPX_OK;
+    }
     if (k == 7) { launch_sep_small_c<7>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<7>"); return IPX_OK; }
 
     if (k >= 9 && k <= 31)                                          // int8 MFMA kernel, ipx_sepmfma.hip (VALU fallback: ipx_sepbig.hip)
