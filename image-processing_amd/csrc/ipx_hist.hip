@@ -252,7 +252,8 @@ unsigned blocks_per_image(int n, int h, int w, unsigned slots = 1024)
     const uint64_t bytes = (uint64_t)h * (uint64_t)w;
     uint64_t by_work = (bytes + 65535) / 65536;
     if (const char* e = getenv("IPX_HIST_SLOTS")) { if (atoi(e) > 0) slots = (unsigned)atoi(e); }   // dev knob
-    uint64_t by_chip = (slots + (uint64_t)n - 1) / (uint64_t)n;  // 256 CUs x resident blocks per CU: one even round
+    uint64_t by_chip = slots / (uint64_t)n;                      // 256 CUs x resident blocks per CU: ONE round (rounding up
+                                                                 // put e.g. 24 images x 22 blocks = 528 blocks on 512 slots)
     uint64_t b = by_work < by_chip ? by_work : by_chip;
     return (unsigned)(b < 1 ? 1 : b);
 }
