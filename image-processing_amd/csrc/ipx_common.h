@@ -50,12 +50,17 @@ __device__ __forceinline__ void st16_nt(uint8_t* p, u32x4 v) { __builtin_nontemp
 template <bool NT> __device__ __forceinline__ u32x4 ld16x(const uint8_t* p) { return NT ? ld16_nt(p) : ld16(p); }
 template <bool NT> __device__ __forceinline__ void st16x(uint8_t* p, u32x4 v) { if (NT) st16_nt(p, v); else st16(p, v); }
 
-// Cache policy of the streaming kernels: small and medium working sets are left to the default policy (the next
-// kernel of a pipeline finds them in the 256 MiB Infinity Cache); very large ones are streamed with nt.  Measured on
-// 16 x 4K frames (scripts/opbench.py): nt wins on an 800 MB table pass (132 vs 143 us) and loses on a 530 MB
-// BGR->gray (106 vs 98 us) and on 266 MB gray passes.  Threshold in bytes of source + destination touched by one
-// call, default 600 MiB; IPX_NT_BYTES overrides it (0 = always nt, huge = never).
-bool ipx_use_nt(uint64_t bytes_touched);
+// Cache policy of the streaming kernels: a pass whose working set fits the 256 MiB Infinity Cache is left to the default
+// policy (the next kernel of a pipeline finds its data there); larger ones stream with nt.  The crossovers were
+// measured per call site on batches of 4K frames (scripts/dev/ntprobe.py), in bytes of source + destination touched:
+//   table pass                    ~300 MB  (16 gray frames: default 2.58 vs nt 2.81 us/frame; 20 frames: 3.21 vs 2.78)
+//   histogram -> table (gray)     ~460 MB  (the histogram pass should leave the image for the table pass: 24 frames
+//                                           4.39 vs 4.62, 32 frames 4.71 vs 4.45)
+//   BGR -> gray + histogram       ~420 MB of source (20 frames: 9.18 vs 8.88)
+//   BGR -> gray                   always nt stores (never worse)
+// IPX_NT_BYTES overrides every threshold (0 = always nt, huge = never).
+constexpr uint64_t kNtLut = 300ull << 20, kNtHistThenLut = 440ull << 20, kNtGrayHist = 400ull << 20, kNtAlways = 0;
+bool ipx_use_nt(uint64_t bytes_touched, uint64_t site_threshold);
 
 // gray = (3735 B + 19235 G + 9798 R + 16384) >> 15   (OpenCV RGB2Gray<uchar>, Q15)
 __device__ __forceinline__ uint32_t gray_q15(uint32_t b, uint32_t g, uint32_t r)

@@ -41,13 +41,13 @@ int ipx_check_image_args(const char* fn, const void* src, const void* dst, int n
     return IPX_OK;
 }
 
-bool ipx_use_nt(uint64_t bytes_touched)
+bool ipx_use_nt(uint64_t bytes_touched, uint64_t site_threshold)
 {
-    static const long long thr = [] {
+    static const long long env_thr = [] {
         const char* v = getenv("IPX_NT_BYTES");
-        return v && *v ? atoll(v) : (long long)600 << 20;
+        return v && *v ? atoll(v) : -1ll;
     }();
-    return (long long)bytes_touched >= thr;
+    return bytes_touched >= (env_thr >= 0 ? (uint64_t)env_thr : site_threshold);
 }
 
 extern "C" {

@@ -290,7 +290,7 @@ int launch_partial(hipStream_t st, const uint8_t* src, int n, int h, int w, int6
     if (bpi > g.units_per_img) bpi = g.units_per_img;     // strided rows: fewer units than bytes/64K suggests
     *nparts = bpi;
     // the histogram pass reads what the table pass re-reads right after: keep small batches in the Infinity Cache
-    if (ipx_use_nt(2ull * (uint64_t)n * h * w))
+    if (ipx_use_nt(2ull * (uint64_t)n * h * w, kNtHistThenLut))
         hipLaunchKernelGGL(hist_partial_kernel<true>, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, partial);
     else
         hipLaunchKernelGGL(hist_partial_kernel<false>, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, partial);
@@ -422,7 +422,7 @@ int ipx_bgr2gray_equalize_u8(void* stream, const uint8_t* src, uint8_t* gray, ui
     unsigned bpi = blocks_per_image(n, h, w, 512);
     if (bpi > blocks_per_image(n, h, w)) bpi = blocks_per_image(n, h, w);
     if (bpi > g.units_per_img) bpi = g.units_per_img;
-    const bool nt = ipx_use_nt((uint64_t)n * h * w * src_channels);
+    const bool nt = ipx_use_nt((uint64_t)n * h * w * src_channels, kNtGrayHist);
     auto k = src_channels == 3 ? (nt ? gray_hist_kernel<3, true> : gray_hist_kernel<3, false>)
                                : (nt ? gray_hist_kernel<4, true> : gray_hist_kernel<4, false>);
     hipLaunchKernelGGL(k, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, gray, g, ws.partial);

@@ -202,7 +202,7 @@ int launch_lut(const char* fn, void* stream, const uint8_t* src, uint8_t* dst, i
     hipStream_t st = (hipStream_t)stream;
     LutArg la{};
     if (lut_host) __builtin_memcpy(la.w, lut_host, 256);
-    const bool nt = ipx_use_nt(2ull * (uint64_t)n * h * w * c);
+    const bool nt = ipx_use_nt(2ull * (uint64_t)n * h * w * c, kNtLut);
     for (int i0 = 0; i0 < n; i0 += 65535) {
         const int nb = n - i0 < 65535 ? n - i0 : 65535;
         const uint8_t* s = src + (int64_t)i0 * s_img;
@@ -231,7 +231,7 @@ int launch_gray(const char* fn, void* stream, const uint8_t* src, uint8_t* dst, 
     hipStream_t st = (hipStream_t)stream;
     LutArg la{};
     if (lut_host) __builtin_memcpy(la.w, lut_host, 256);
-    const bool nt = ipx_use_nt((uint64_t)n * h * w * (sc + 1));
+    const bool nt = ipx_use_nt((uint64_t)n * h * w * (sc + 1), kNtAlways);
     for (int i0 = 0; i0 < n; i0 += 65535) {
         const int nb = n - i0 < 65535 ? n - i0 : 65535;
         const uint8_t* s = src + (int64_t)i0 * s_img;
