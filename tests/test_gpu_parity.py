@@ -479,3 +479,36 @@ def test_full_size_rank_and_lee_filters(dev):
     two = dev_t(img[500:900, 1000:2600], dev)
     m = ops.median_blur(two, 7)
     assert set(torch.unique(m).tolist()) <= {0, 255}
+
+
+def test_streaming_variants_of_the_kernels_in_a_child_process(dev):
+    """The nt (streaming) template variants are chosen by working-set size, far above what tests use; IPX_NT_BYTES=0
+    forces them (read once per process, hence the child process): same pixels."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = r'''
+import sys, numpy as np, torch
+sys.path[:0] = [%r, %r, %r]
+import oracle as O, ipx.ops as ops, ipx.luts as luts
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(3)
+for shape in [(1, 1), (7, 1), (33, 70), (40, 342), (18, 2051), (300, 411)]:
+    g = rng.integers(0, 256, shape, dtype=np.uint8)
+    c = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+    tg, tc = torch.from_numpy(g).to(dev), torch.from_numpy(c).to(dev)
+    lut = luts.gamma(0.6)
+    assert np.array_equal(ops.apply_lut(tg, lut).cpu().numpy(), lut[g])
+    assert np.array_equal(ops.apply_lut(tc, lut).cpu().numpy(), lut[c])
+    assert np.array_equal(ops.hist(tg).cpu().numpy().astype(np.uint32).reshape(256), O.hist_u8(g))
+    assert np.array_equal(ops.equalize_hist(tg).cpu().numpy(), O.equalize_hist_u8(g))
+    gray, eq = ops.bgr2gray_equalize(tc)
+    assert np.array_equal(gray.cpu().numpy(), O.bgr2gray_u8(c))
+    assert np.array_equal(eq.cpu().numpy(), O.equalize_hist_u8(O.bgr2gray_u8(c)))
+    assert np.array_equal(ops.bgr2gray_lut(tc, lut).cpu().numpy(), lut[O.bgr2gray_u8(c)])
+print("ok")
+''' % (os.path.join(here, "..", "image-processing_amd"), os.path.join(here, "..", "oracle"), here)
+    env = dict(os.environ, IPX_NT_BYTES="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
