@@ -460,11 +460,11 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
     // 2r halo rows every segment re-reads
     int seg = env_int("IPX_SEG_ROWS", 0);
     if (seg <= 0) {
-        const int64_t rows_total = (int64_t)n * (g.nstrips ? g.nstrips : 1) * h;
-        seg = (int)(rows_total / 16384);
-        const int lo = r <= 1 ? 16 : r == 2 ? 24 : 48, hi = 128;      // measured optima on 16 x 4K (scripts/opbench.py)
-        if (seg < lo) seg = lo;
-        if (seg > hi) seg = hi;
+        // measured optima (scripts/opbench.py on 16 x 4K, scripts/dev/cfg3ops.py on 128 x 1080p): they do not grow with
+        // the workload -- a walker copy streams 5.65 TB/s with 12-row segments, 5.3 with 24, 5.2 with 48
+        // (scripts/dev/walkbench3.hip); longer segments only pay where the 2r halo rows are many
+        const int hi = 128;
+        seg = r <= 1 ? 16 : r == 2 ? 24 : 48;
         seg = (seg + gran / 2) / gran * gran;                 // whole loop iterations (rows per unrolled walk step)
         // between one and two rounds of resident waves (256 CUs x 4 SIMDs x ~4 waves) the second round is a long
         // tail: stretch the segments so that everything is resident at once (gray 4K batches: 55 -> 51 us)

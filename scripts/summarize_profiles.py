@@ -29,9 +29,19 @@ for which, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 bench = json.load(open(os.path.join(src, "bench.json")))
 B = bench["config"]["batch_per_gpu"]
 px = B * 2160 * 3840
-alg = {"sep_small_kernel<3, 5>": 6, "conv3_kernel<2, 1>": 2, "conv3_kernel<0, 3>": 6, "gray_hist_kernel<3, false>": 4,
-       "gray_kernel<3, false, false>": 4, "lut_kernel<false, false>": 2, "lut_kernel<true, false>": 2,
-       "hist_partial_kernel<false>": 1}
+alg_by_prefix = {"sep_small_kernel<3, 5>": 6, "conv3_kernel<2, 1>": 2, "conv3_kernel<0, 3>": 6, "gray_hist_kernel<3": 4,
+                 "gray_kernel<3": 4, "lut_kernel<": 2, "hist_partial_kernel<": 1}   # the nt template variants share a row
+
+
+class _Alg:
+    def get(self, k):
+        for pre, v in alg_by_prefix.items():
+            if k.startswith(pre):
+                return v
+        return None
+
+
+alg = _Alg()
 lines = [f"# {name}: per-kernel duration and HBM-side traffic (batch {B} x 3840x2160)", "",
          "Source: `rocprofv3 --kernel-trace --stats` and two `--pmc` passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py`,",
          "collected by scripts/collect_profiles.sh.  Counters are KiB; FETCH_SIZE is doubled (gfx950 reports half the bytes of a",
