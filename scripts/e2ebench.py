@@ -68,3 +68,26 @@ for (h, w) in ((512, 512), (2160, 3840)):
         out[f"{mode}_{w}x{h}"] = rec
         print(mode, f"{w}x{h}", rec, flush=True)
 print(json.dumps(out))
+
+# ---- concurrent clients: the host handles requests on threads (per-thread HIP stream, codec work releases the GIL) ----
+import threading
+app = app_mod.create_app()
+data = png(smooth(2160, 3840, 1))
+def worker(n, out, idx):
+    c = app.test_client()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = c.post("/api/process", data={"mode": "gamma", "gamma": "0.6", "file": (io.BytesIO(data), "x.png")},
+                   content_type="multipart/form-data")
+        assert r.status_code == 200
+    out[idx] = time.perf_counter() - t0
+worker(1, [0], 0)
+for nthreads in (1, 2, 4, 8, 16):
+    res_t = [0.0] * nthreads
+    ths = [threading.Thread(target=worker, args=(3, res_t, i)) for i in range(nthreads)]
+    t0 = time.perf_counter()
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    dt = time.perf_counter() - t0
+    rec = {"clients": nthreads, "requests_per_s": round(3 * nthreads / dt, 1), "MP_per_s": round(3 * nthreads * 8.2944 / dt, 1)}
+    print("concurrent 4K gray gamma requests:", rec, flush=True)
