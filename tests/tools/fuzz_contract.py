@@ -3,13 +3,13 @@ Random requests -- modes, parameter aliases, malformed / missing / out-of-range 
 ipx.app (oracle backend); status, JSON body and decoded pixels must be identical.  Only modes whose arithmetic is numpy
 inside the reference can be compared (gray8, negative, gamma, log, piecewise/stretch, denoise_manual method=lee, unknown
 modes, the 400 paths); OpenCV-backed modes are skipped.
-usage: python scripts/dev/fuzz_contract.py [--n 400] [--seed 0]"""
+usage: python tests/tools/fuzz_contract.py [--n 400] [--seed 0]"""
 import argparse
 import io
 import os
 import sys
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")  # repo root (tests/tools/ -> ../..)
 for p in ("image-processing_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import numpy as np

@@ -3,13 +3,13 @@
 Random shapes (incl. widths around the 16-byte / 1 KiB strip / 128-byte tile edges), channel counts, batch sizes and
 ROW-STRIDED views (a window of a wider buffer), every operator.  Exact equality everywhere.  The fixed-shape cases live
 in tests/test_gpu_parity.py; this looks for the shapes nobody thought of.
-usage: python scripts/dev/fuzz_parity.py [--seconds 90] [--seed 0] [--ops lee,median]"""
+usage: python tests/tools/fuzz_parity.py [--seconds 90] [--seed 0] [--ops lee,median]"""
 import argparse
 import os
 import sys
 import time
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")  # repo root (tests/tools/ -> ../..)
 for p in ("image-processing_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import numpy as np

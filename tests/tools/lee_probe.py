@@ -5,7 +5,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")  # repo root (tests/tools/ -> ../..)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 
