@@ -10,6 +10,7 @@
 //   equalization table with an LDS scan, in float32 exactly as OpenCV does.
 #include "ipx_common.h"
 #include <stdlib.h>
+#include <atomic>
 
 extern "C" int ipx_lut_dev_u8(void*, const uint8_t*, uint8_t*, int, int, int, int, int64_t, int64_t, int64_t, int64_t,
                               const uint8_t*, int64_t);
@@ -251,7 +252,10 @@ unsigned blocks_per_image(int n, int h, int w, unsigned slots = 1024)
 {
     const uint64_t bytes = (uint64_t)h * (uint64_t)w;
     uint64_t by_work = (bytes + 65535) / 65536;
-    if (const char* e = getenv("IPX_HIST_SLOTS")) { if (atoi(e) > 0) slots = (unsigned)atoi(e); }   // dev knob
+#ifdef IPX_DEV
+    static const int env_slots = [] { const char* e = getenv("IPX_HIST_SLOTS"); return e ? atoi(e) : 0; }();   // read once
+    if (env_slots > 0) slots = (unsigned)env_slots;
+#endif
     uint64_t by_chip = slots / (uint64_t)n;                      // 256 CUs x resident blocks per CU: ONE round (rounding up
                                                                  // put e.g. 24 images x 22 blocks = 528 blocks on 512 slots)
     uint64_t b = by_work < by_chip ? by_work : by_chip;
@@ -295,6 +299,50 @@ int launch_partial(hipStream_t st, const uint8_t* src, int n, int h, int w, int6
     else
         hipLaunchKernelGGL(hist_partial_kernel<false>, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, partial);
     IPX_LAUNCH_CHECK("hist_partial_kernel");
+    return IPX_OK;
+}
+
+// hist -> table -> table pass around a workspace laid out by workspace_layout (shared by the allocating and the
+// no-allocation entry points)
+int equalize_with_workspace(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                            int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
+                            uint32_t* hist_out_dev, uint8_t* lut_out_dev, uint8_t* workspace)
+{
+    Workspace ws;
+    workspace_layout(n, h, w, &ws, workspace);
+    uint8_t* lut = lut_out_dev ? lut_out_dev : ws.lut;
+    unsigned nparts = 0;
+    if (int rc = launch_partial(st, src, n, h, w, s_row, s_img, ws.partial, &nparts)) return rc;
+    hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, st, ws.partial, nparts,
+                       (const uint32_t*)nullptr, hist_out_dev, lut);
+    IPX_LAUNCH_CHECK("hist_finish_kernel");
+    return ipx_lut_dev_u8((void*)st, src, dst, n, h, w, 1, s_row, s_img, d_row, d_img, lut, 256);
+}
+
+// ---- scratch of the no-allocation entry point ---------------------------------------------------------------------
+// One array per GPU, held until the process ends.  `scratch` is a host-side stand-in for the symbol, NOT a device
+// address: host code only ever uses the pointer hipGetSymbolAddress returns for the current device.
+constexpr size_t kScratchBytes = IPX_NOALLOC_SCRATCH_BYTES;           // partial counts (<= 1 MiB) + histograms + tables of <= 256 images
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) uint8_t scratch[kScratchBytes];
+std::atomic<uint8_t*> g_scratch_ptr[kMaxDevices];      // per device, filled on the first call with that device current
+                                                        // (two racing first calls both look up the same address)
+
+int scratch_for_current_device(const char* fn, uint8_t** out)
+{
+    int dev = -1;
+    IPX_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: device index %d outside 0..%d", fn, dev, kMaxDevices - 1);
+    uint8_t* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return ipx_fail(IPX_ERR_HIP, "%s: hipGetSymbolAddress(scratch) failed on device %d: %s", fn, dev, hipGetErrorString(e));
+        ptr = (uint8_t*)p;
+        g_scratch_ptr[dev].store(ptr, std::memory_order_release);
+    }
+    *out = ptr;
     return IPX_OK;
 }
 
@@ -365,24 +413,33 @@ int ipx_equalize_hist_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     } else if (workspace_bytes < need) {
         return ipx_fail(IPX_ERR_INVALID, "ipx_equalize_hist_u8: workspace %zu < %zu bytes needed", workspace_bytes, need);
     }
-    Workspace ws;
-    workspace_layout(n, h, w, &ws, (uint8_t*)workspace);
-    uint8_t* lut = lut_out_dev ? lut_out_dev : ws.lut;
-    unsigned nparts = 0;
-    int rc = launch_partial(st, src, n, h, w, src_row_stride, src_img_stride, ws.partial, &nparts);
-    if (rc == IPX_OK) {
-        hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, st, ws.partial, nparts,
-                           (const uint32_t*)nullptr, hist_out_dev, lut);
-        if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "launch of hist_finish_kernel failed");
-    }
-    if (rc == IPX_OK)
-        rc = ipx_lut_dev_u8(stream, src, dst, n, h, w, 1, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride,
-                            lut, 256);
+    int rc = equalize_with_workspace(st, src, dst, n, h, w, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride,
+                                     hist_out_dev, lut_out_dev, (uint8_t*)workspace);
     if (own) {
         hipError_t e = hipFreeAsync(own, st);
         if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
     }
     return rc;
+}
+
+int ipx_equalize_hist_noalloc_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                                 int64_t src_row_stride, int64_t src_img_stride, int64_t dst_row_stride, int64_t dst_img_stride,
+                                 uint32_t* hist_out_dev, uint8_t* lut_out_dev)
+{
+    const char* fn = "ipx_equalize_hist_noalloc_u8";
+    if (int rc = ipx_check_image_args(fn, src, dst, n, h, w, 1, 1, src_row_stride, src_img_stride,
+                                      dst_row_stride, dst_img_stride)) return rc;
+    if (int rc = check_hist_args(fn, src, n, h, w, src_row_stride, src_img_stride)) return rc;
+    const size_t need = workspace_layout(n, h, w, nullptr, nullptr);
+    if (need > kScratchBytes)
+        return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: a batch of %d images needs %zu bytes of scratch, the built-in array holds %zu "
+                        "(use ipx_equalize_hist_u8 with a workspace)", fn, n, need, kScratchBytes);
+    uint8_t* ws = nullptr;
+    if (int rc = scratch_for_current_device(fn, &ws)) return rc;
+    // Nothing in the scratch has to start at zero: every partial count, histogram bin and table entry that is read
+    // is written first by this call's own kernels, so the previous call's contents are simply overwritten.
+    return equalize_with_workspace((hipStream_t)stream, src, dst, n, h, w, src_row_stride, src_img_stride,
+                                   dst_row_stride, dst_img_stride, hist_out_dev, lut_out_dev, ws);
 }
 
 int ipx_bgr2gray_equalize_u8(void* stream, const uint8_t* src, uint8_t* gray, uint8_t* dst, int n, int h, int w, int src_channels,

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("IPX_LIB", os.path.join(_HERE, "..", "lib", "libipx.so
 
 IPX_OK, IPX_ERR_INVALID, IPX_ERR_HIP, IPX_ERR_UNSUPPORTED = 0, -1, -2, -3
 MAX_GAUSS_K = 255
+NOALLOC_SCRATCH_BYTES = 1536 * 1024
 
 
 class IpxError(RuntimeError):
@@ -37,6 +38,7 @@ SIGNATURES = {
     "ipx_hist_u8": (_i, [_vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _sz]),
     "ipx_equalize_lut_u8": (_i, [_vp, _vp, _i, _vp]),
     "ipx_equalize_hist_u8": (_i, _IMG + _STR + [_vp, _vp, _vp, _sz]),
+    "ipx_equalize_hist_noalloc_u8": (_i, _IMG + _STR + [_vp, _vp]),
     "ipx_bgr2gray_equalize_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _sz]),
     "ipx_laplacian_sharpen_u8": (_i, _IMG + [_i] + _STR + [_vp, _vp]),
     "ipx_box3_u8": (_i, _IMG + [_i] + _STR + [_vp, _vp]),

@@ -195,6 +195,24 @@ def equalize_hist(src: torch.Tensor, return_aux: bool = False):
     return (res, hst, lut) if return_aux else res
 
 
+def equalize_hist_noalloc(src: torch.Tensor, out: torch.Tensor, hist_out: Optional[torch.Tensor] = None,
+                          lut_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """cv2.equalizeHist through the entry point that allocates nothing (ipx_equalize_hist_noalloc_u8): the caller
+    passes the output (and optional (N,256) int32 histogram / uint8 table) tensors; the scratch is the library's
+    built-in per-GPU array.  Calls that overlap on one GPU race -- keep them on one stream."""
+    s, d = _gray(src), _gray(out)
+    if (d.n, d.h, d.w) != (s.n, s.h, s.w) or d.t.data_ptr() != (out.data_ptr() if out.ndim else 0):
+        raise ValueError("out: a writable tensor of the source's shape expected (no copy may be made of it)")
+    for t, dt, nm in ((hist_out, torch.int32, "hist_out"), (lut_out, torch.uint8, "lut_out")):
+        if t is not None and (t.dtype != dt or not t.is_cuda or not t.is_contiguous() or t.numel() != s.n * 256):
+            raise ValueError(f"{nm}: contiguous {dt} CUDA tensor with N*256 entries expected")
+    with torch.cuda.device(s.t.device):
+        _lib.call("ipx_equalize_hist_noalloc_u8", _stream(), s.ptr, d.ptr, s.n, s.h, s.w, s.row, s.img, d.row, d.img,
+                  hist_out.data_ptr() if hist_out is not None else None,
+                  lut_out.data_ptr() if lut_out is not None else None)
+    return out
+
+
 def bgr2gray_equalize(src: torch.Tensor, return_aux: bool = False):
     """server.py:245-246 on a colour image in one pass over the source: returns (gray, equalized[, hist, lut])."""
     s = _Img(src)

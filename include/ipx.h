@@ -111,6 +111,21 @@ int ipx_equalize_hist_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
                          uint32_t* hist_out_dev, uint8_t* lut_out_dev,
                          void* workspace, size_t workspace_bytes);
 
+/* ipx_equalize_hist_u8 for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments and results as
+ * ipx_equalize_hist_u8 minus the workspace: the scratch (per-block partial counts, histograms, tables) is a
+ * file-scope __device__ array of IPX_NOALLOC_SCRATCH_BYTES inside the library, one copy per GPU, held until the
+ * process ends; the call makes no hipMalloc / hipFree / allocating library call.  Limit: batches whose
+ * ipx_hist_workspace_bytes(n, h, w) exceeds IPX_NOALLOC_SCRATCH_BYTES are rejected with IPX_ERR_UNSUPPORTED
+ * (any batch of up to 256 images fits, whatever the image size).  All calls on one GPU share that GPU's array: calls that
+ * overlap in time on one GPU (two streams, two threads) race -- serialise them.  Nothing in the array has to
+ * start at zero (every word that is read is written first by the same call). */
+#define IPX_NOALLOC_SCRATCH_BYTES (1536u * 1024u)
+int ipx_equalize_hist_noalloc_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                                 int64_t src_row_stride, int64_t src_img_stride,
+                                 int64_t dst_row_stride, int64_t dst_img_stride,
+                                 uint32_t* hist_out_dev, uint8_t* lut_out_dev);
+
 /* Fused server.py:245-246 for colour input: gray = cv2.cvtColor(img, BGR2GRAY) (kept: `gray` is an output, n x h x w)
  * and dst = cv2.equalizeHist(gray).  The histogram is taken while the gray image is written, so the source is read
  * once (3 + 1 + 1 + 1 bytes per pixel instead of 3 + 1 and 1 + 1 + 1).  dst may alias gray (in-place table pass).
