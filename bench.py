@@ -59,6 +59,32 @@ def cpu_baseline(frames: int, passes: int):
                       "A port, not the reference: OpenCV is absent from this image"}
 
 
+def spawn_ranks(n: int) -> int:
+    """Run `n` ranks of this script (one per GPU) as child processes and relay rank 0's output; returns the exit code.
+    The parent makes no GPU call (children are started with subprocess, nothing is exec'd over an initialised process)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0 = procs[0].communicate()[0]
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +95,16 @@ def main():
     ap.add_argument("--order", default="gauss_first", choices=["gauss_first", "geq_first", "sobel_mid"], help="order of the three independent ops inside a step")
     ap.add_argument("--ops-table", action="store_true", help="also time ops that are not part of the step, back to back")
     args = ap.parse_args()
+
+    # --gpus N without a launcher: start N ranks of this script as CHILD processes, before this process touches the GPU
+    # (it never does), wait for them and pass rank 0's JSON line through.  Under torchrun (WORLD_SIZE set) --gpus must agree.
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={env_world} set by the launcher")
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -108,7 +144,7 @@ def main():
 
     DOMINANT = 0                                                  # index into the unordered op list: the 5x5 Gaussian
 
-    def step(ev=None, only=None):
+    def step(ev=None, only=None, src=None):
         """One pass of the pipeline over the resident batch; `ev` (optional) receives HIP events at op boundaries,
         recorded on the stream the kernels are launched on (torch's current stream): around every op, or with `only`
         around that op alone (ev[0], ev[1]).  An event between two kernels keeps them from overlapping at their edges
@@ -116,15 +152,16 @@ def main():
         the two around the dominant kernel.  The three ops are independent except that Sobel needs the gray image;
         --order only changes which runs first."""
         res = {}
+        src = bgr if src is None else src
         if ev is not None and only is None:
             ev[0].record()
         for j, i in enumerate(order):
             if ev is not None and only == i:
                 ev[0].record()
             if i == 0:
-                res["g5"] = ops.gaussian_blur(bgr, 5)
+                res["g5"] = ops.gaussian_blur(src, 5)
             elif i == 1:
-                res["gray"], res["eq"] = ops.bgr2gray_equalize(bgr)   # cvtColor + equalizeHist, histogram taken while gray is written
+                res["gray"], res["eq"] = ops.bgr2gray_equalize(src)   # cvtColor + equalizeHist, histogram taken while gray is written
             else:
                 res["sb"] = ops.sobel(res["gray"])
             if ev is not None and only is None:
@@ -157,6 +194,15 @@ def main():
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     for i in range(args.steps):
         step(events[i])
+    torch.cuda.synchronize()
+    # the LITERAL configs[1]: ONE 4K image per launch (what a single /api/process request sees); same event scheme
+    one = bgr[:1]
+    lat_steps = 50
+    for _ in range(5):
+        step(src=one)
+    lat_events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(lat_steps)]
+    for i in range(lat_steps):
+        step(lat_events[i], src=one)
     torch.cuda.synchronize()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -197,6 +243,14 @@ def main():
             else:
                 s = sum(events[i][j].elapsed_time(events[i][j + 1]) for i in range(args.steps)) / args.steps * 1e-3
                 kernels[name] = row(kern, bpp, s, "HIP events around every op in K instrumented steps after the timed region (in-pipeline)")
+        latency_b1_us = {}
+        for j, (name, _, _) in enumerate(STEP_OPS):
+            ts = sorted(lat_events[i][j].elapsed_time(lat_events[i][j + 1]) for i in range(lat_steps))
+            latency_b1_us[name] = round(ts[len(ts) // 2] * 1e3, 1)
+        ts = sorted(lat_events[i][0].elapsed_time(lat_events[i][3]) for i in range(lat_steps))
+        latency_b1_us["step"] = round(ts[len(ts) // 2] * 1e3, 1)
+        latency_b1_us["note"] = ("median over 50 steps of ONE 3840x2160 RGB image per launch, HIP events around every op; "
+                                 "one image is 25 MB: launch + ramp dominate, not bandwidth")
         if args.ops_table:
             gray = ops.bgr2gray(bgr)
             for name, kern, bpp, fn in [
@@ -208,20 +262,33 @@ def main():
                 ("laplacian_sharpen_bgr", "conv3_kernel<SHARPEN,3>", 6, lambda: ops.laplacian_sharpen(bgr)),
                 ("lut_gray", "lut_kernel<true>", 2, lambda: ops.apply_lut(gray, list(range(255, -1, -1)))),
                 ("lut_bgr", "lut_kernel<true>", 6, lambda: ops.apply_lut(bgr, list(range(255, -1, -1)))),
+                # SURVEY.md section 8(f) kernels, 2 B/px algorithmic each (gray in, gray out)
+                ("lee_w3", "lee_kernel", 2, lambda: ops.lee_filter(gray, 3)),
+                ("lee_w5", "lee_kernel", 2, lambda: ops.lee_filter(gray, 5)),
+                ("lee_w31", "lee_kernel", 2, lambda: ops.lee_filter(gray, 31)),
+                ("erode_3", "morph_kernel", 2, lambda: ops.erode(gray, ops.ellipse_se(3))),
+                ("dilate_5", "morph_kernel", 2, lambda: ops.dilate(gray, ops.ellipse_se(5))),
+                ("median_3", "median_small_kernel<3>", 2, lambda: ops.median_blur(gray, 3)),
+                ("median_5", "median_small_kernel<5>", 2, lambda: ops.median_blur(gray, 5)),
+                ("median_31", "median_hist_kernel", 2, lambda: ops.median_blur(gray, 31)),
             ]:
                 kernels[name] = row(kern, bpp, time_op(fn), "20 back-to-back launches between two HIP events")
         dom_name = max(STEP_OPS, key=lambda o: kernels[o[0]]["us_per_launch"])[0]
         dom = kernels[dom_name]
-        traffic = None
+        # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): read from the committed
+        # record of the same kernel at the same batch, and labelled with where it came from
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(dom_name) if tj.get("batch_per_gpu", 16) == B else None    # measured per launch at that batch
+                if tj.get("batch_per_gpu", 16) == B and tj.get(dom_name) is not None:
+                    traffic = tj[dom_name]
+                    traffic_source = f"profiles/pmc_traffic.json ({tj.get('source', 'rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes')}; recorded at {tj.get('recorded_at', 'round 1')})"
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "op": dom_name, "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": dom["frac_of_8TBps"], "traffic": traffic,
+                    "unit": "GB/s", "frac": dom["frac_of_8TBps"], "traffic": traffic, "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": px * dom["algorithmic_B_per_px"], "launch_us": dom["us_per_launch"],
                     "step_algorithmic_GBps": round(px * sum(o[2] for o in STEP_OPS) / (dt / args.steps) / 1e9, 1)}
         cpu = cpu_baseline(4, args.cpu_sample) if (args.cpu_sample > 0 and world == 1) else None
@@ -234,7 +301,7 @@ def main():
                                    "(incl. BGR->gray), batch resident in HBM",
                        "batch_per_gpu": B, "image": "3840x2160x3 u8 BGR interleaved",
                        "parallelism": f"{world} x one process per GPU, images sharded, no collective"},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "latency_b1_us": latency_b1_us,
         }
     if world > 1:
         dist.barrier()

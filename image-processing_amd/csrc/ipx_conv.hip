@@ -13,13 +13,13 @@
 // Neighbouring strips are consecutive work items and the block->item map is XCD-aware so that they share an L2.
 // 9..31 taps: ipx_sepmfma.hip (both passes as banded int8 matrix products on the MFMA units; taps above 127 fall back
 // to ipx_sepbig.hip, a row-pass kernel + column-pass kernel around a Q8.8 scratch image).  Anything larger
-// (and k = 1) goes through the simple generic two-pass path at the bottom of this file.
+// goes through the simple generic two-pass path at the bottom of this file; k = 1 is a copy.
 #include "ipx_common.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include "ipx_fields.h"
-#include <stdlib.h>
-#include <vector>
+
+extern "C" int ipx_lut_u8(void*, const uint8_t*, uint8_t*, int, int, int, int, int64_t, int64_t, int64_t, int64_t, const uint8_t*);
 
 int ipx_sep_mfma(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
                  int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
@@ -41,7 +41,9 @@ struct ConvGeom {
     unsigned border_total;             // n * h * nb
     const uint8_t* top;                // r halo rows above row 0 (row -r first), or null = reflect
     const uint8_t* bot;                // r halo rows below row h-1, or null = reflect
-    unsigned long long* trace;         // dev (IPX_CONV_TRACE): per wave start / end time stamps, else null
+#ifdef IPX_DEV
+    unsigned long long* trace;         // dev build (IPX_CONV_TRACE): per wave start / end time stamps, else null
+#endif
 };
 
 // Source row `y` of the image (y may lie outside [0,h)): halo row if provided, else REFLECT_101.
@@ -297,10 +299,14 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
                                                              ConvGeom g, Taps<K> t)
 {
     constexpr int R = K / 2, NP = (K + 1) / 2;
+#ifdef IPX_DEV
     const unsigned trace_id = 2u * (blockIdx.x * (unsigned)g.wpb + (threadIdx.x >> 6));
+#endif
     if (blockIdx.x >= g.main_blocks) {                       // ---- border bytes, one per thread
         unsigned img; int y, b;
+#ifdef IPX_DEV
         if (g.trace && (threadIdx.x & 63u) == 0) g.trace[trace_id] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (!border_item(g, blockIdx.x - g.main_blocks, img, y, b)) return;
         const uint8_t* simg = src + (int64_t)img * g.s_img;
         const int px = b / C, ch = b - px * C;
@@ -317,7 +323,9 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
             acc += tap_y<K>(t, i) * hsum;
         }
         dst[(int64_t)img * g.d_img + (int64_t)y * g.d_row + b] = (uint8_t)(acc >> 16);
+#ifdef IPX_DEV
         if (g.trace && (threadIdx.x & 63u) == 0) g.trace[trace_id + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
         return;
     }
     unsigned img; int y0, y1, lane0;
@@ -328,8 +336,10 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     typedef Win<C, R> WR;
+#ifdef IPX_DEV
     const bool tracer = g.trace && (threadIdx.x & 63u) == (gl == 1 ? 1u : 0u);
     if (tracer) g.trace[trace_id] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int nrows = y1 - y0;
     const int ys = y0;
@@ -384,7 +394,9 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
             }
         }
     }
+#ifdef IPX_DEV
     if (tracer) g.trace[trace_id + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---- generic two-pass path (any odd K <= IPX_MAX_GAUSS_K) -----------------------------------------------
@@ -430,11 +442,19 @@ __global__ __launch_bounds__(256) void sep_cols_kernel(const uint16_t* __restric
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
+// Tuning knobs exist in development builds only (make EXTRA=-DIPX_DEV) and are read once per process.
+#ifdef IPX_DEV
 int env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
 }
+int dev_seg_rows() { static const int v = env_int("IPX_SEG_ROWS", 0); return v; }
+int dev_wpb() { static const int v = env_int("IPX_WPB", 0); return v; }
+#else
+constexpr int dev_seg_rows() { return 0; }
+constexpr int dev_wpb() { return 0; }
+#endif
 
 // hd4 = 4 * ceil(r*c/4): halo bytes a main-region lane reads on either side (<= 16)
 int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c, int r, int max_wpb, int gran,
@@ -447,7 +467,9 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
     g.h = h; g.w = w; g.L = w * c;
     g.s_row = s_row; g.s_img = s_img; g.d_row = d_row; g.d_img = d_img;
     g.top = top; g.bot = bot;
+#ifdef IPX_DEV
     g.trace = nullptr;
+#endif
     const int hd4 = 4 * ((r * c + 3) / 4);
     // main-region lane i covers bytes [16 + 16 i, 32 + 16 i) and reads hd4 bytes on either side of them
     g.nlanes = g.L >= 32 + hd4 ? (g.L - 32 - hd4) / 16 + 1 : 0;
@@ -458,7 +480,7 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
     g.nstrips = g.nlanes ? (g.nlanes + 1 + 63) / 64 : 0;
     // rows per segment: short enough for >= ~4 waves of work per wave slot, long enough to amortise the
     // 2r halo rows every segment re-reads
-    int seg = env_int("IPX_SEG_ROWS", 0);
+    int seg = dev_seg_rows();
     if (seg <= 0) {
         // measured optima (scripts/opbench.py on 16 x 4K, scripts/dev/cfg3ops.py on 128 x 1080p): they do not grow with
         // the workload -- a walker copy streams 5.65 TB/s with 12-row segments, 5.3 with 24, 5.2 with 48
@@ -480,7 +502,7 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
     g.seg_rows = seg;
     g.nsegs = (h + seg - 1) / seg;
     // waves per block: the strips of one row segment split evenly over as few blocks as max_wpb allows
-    int want = env_int("IPX_WPB", 0);
+    int want = dev_wpb();
     if (want <= 0) want = 4;
     if (want > max_wpb) want = max_wpb;
     g.blocks_per_seg = g.nstrips ? (g.nstrips + want - 1) / want : 1;
@@ -585,9 +607,15 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     }
     if (sx != 256 || sy != 256) return ipx_fail(IPX_ERR_INVALID, "%s: taps must sum to 256 (got %u, %u)", fn, sx, sy);
     hipStream_t st = (hipStream_t)stream;
+    if (k == 1) {                                                     // the single tap is 256 = 1.0: a copy (cv2 too)
+        uint8_t ident[256];
+        for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
+        return ipx_lut_u8(stream, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, ident);
+    }
     if (k == 3) { launch_sep_small_c<3>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<3>"); return IPX_OK; }
     if (k == 5) {
-        const char* tf = getenv("IPX_CONV_TRACE");                    // dev knob: dump per-wave start / end stamps (100 MHz)
+#ifdef IPX_DEV
+        const char* tf = getenv("IPX_CONV_TRACE");                    // dev build: dump per-wave start / end stamps (100 MHz)
         if (tf) {
             const size_t nw = (size_t)conv_grid(g) * g.wpb, bytes = 2 * nw * sizeof(unsigned long long);
             IPX_HIP(hipMalloc((void**)&g.trace, bytes));
@@ -601,6 +629,7 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
             IPX_HIP(hipFree(g.trace));
             return IPX_OK;
         }
+#endif
         launch_sep_small_c<5>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<5>"); return IPX_OK;
     }
     if (k == 7) { launch_sep_small_c<7>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<7>"); return IPX_OK; }
@@ -608,7 +637,7 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     if (k >= 9 && k <= 31)                                          // int8 MFMA kernel, ipx_sepmfma.hip (VALU fallback: ipx_sepbig.hip)
         return ipx_sep_mfma(st, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, kx_q8, ky_q8, k, top_halo, bottom_halo);
 
-    // generic two-pass path through a Q8.8 scratch image of (h + 2r) rows per image (k = 1 and k > 31)
+    // generic two-pass path through a Q8.8 scratch image of (h + 2r) rows per image (k > 31)
     if (n > 65535 || h + k > 65535) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: n or h too large for the two-pass path", fn);
     const int r = k / 2;
     const size_t tmp_bytes = (size_t)n * (size_t)(h + 2 * r) * (size_t)g.L * sizeof(uint16_t);
@@ -634,10 +663,9 @@ int ipx_gaussian_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
                          int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, int k,
                          const uint8_t* top_halo, const uint8_t* bottom_halo)
 {
-    std::vector<uint16_t> q(k > 0 ? k : 1);
-    if (int rc = ipx_gauss_kernel_q8(k, 0.0, q.data())) return rc;
-    return ipx_sep_filter_q8_u8(stream, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, q.data(), q.data(), k,
-                                top_halo, bottom_halo);
+    uint16_t q[IPX_MAX_GAUSS_K];
+    if (int rc = ipx_gauss_kernel_q8(k, 0.0, q)) return rc;          // rejects k outside 1..IPX_MAX_GAUSS_K before q is written
+    return ipx_sep_filter_q8_u8(stream, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, q, q, k, top_halo, bottom_halo);
 }
 
-}  // namespace
+}  // extern "C"

@@ -5,7 +5,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -76,7 +75,7 @@ int ipx_gauss_kernel_q8(int k, double sigma, uint16_t* out)
     if (!out) return ipx_fail(IPX_ERR_INVALID, "ipx_gauss_kernel_q8: null output");
     if (k < 1 || (k & 1) == 0 || k > IPX_MAX_GAUSS_K)
         return ipx_fail(IPX_ERR_INVALID, "ipx_gauss_kernel_q8: k=%d must be odd and in 1..%d", k, IPX_MAX_GAUSS_K);
-    std::vector<double> f(k);
+    double f[IPX_MAX_GAUSS_K];                  // (no heap: nothing here may throw across the C ABI)
     static const double t3[] = {0.25, 0.5, 0.25};
     static const double t5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625};
     static const double t7[] = {0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125};
@@ -87,11 +86,18 @@ int ipx_gauss_kernel_q8(int k, double sigma, uint16_t* out)
     if (tab) {
         for (int i = 0; i < k; ++i) f[i] = tab[i];
     } else {
-        const double sg = sigma > 0 ? sigma : 0.15 * k + 0.35;
-        const double scale2 = -0.5 / (sg * sg);
-        double sum = 0;
-        for (int i = 0; i < k; ++i) { const double x = i - (k - 1) * 0.5; f[i] = exp(scale2 * x * x); sum += f[i]; }
-        for (int i = 0; i < k; ++i) f[i] /= sum;
+        // getGaussianKernelBitExact's order of operations: sigma by ONE fused multiply-add, x = 2 (i - (k-1)/2) as an
+        // integer with scale -0.125 / sigma^2, only the first half of the taps summed, sum = 2 * half + 1 (the centre tap
+        // is exp(0)), every tap MULTIPLIED by 1 / sum.  (OpenCV evaluates exp in softfloat, this uses libm's: both are
+        // within an ulp; tests/test_oracle_golden.py shows no tap of k <= 255 sits near enough to a rounding tie for
+        // that to matter.)
+        const double sg = sigma > 0 ? sigma : fma((double)k, 0.15, 0.35);
+        const double scale2 = -0.125 / (sg * sg);
+        double half = 0;
+        for (int i = 0, x = 1 - k; i < k / 2; ++i, x += 2) { f[i] = exp((double)(x * x) * scale2); half += f[i]; }
+        const double mul1 = 1.0 / (half * 2.0 + 1.0);
+        for (int i = 0; i < k / 2; ++i) f[i] *= mul1;
+        f[k / 2] = mul1;
     }
     double err = 0;
     long acc = 0;

@@ -45,10 +45,18 @@ struct MGeom {
     unsigned npatches;
     const uint8_t* top;
     const uint8_t* bot;
-    int ablate;                                      // dev: skip phases (timing only, results wrong)
     int fast32;                                      // row strides small enough for 32-bit in-tile byte offsets
-    long long* prof;                                 // dev: phase time stamps of block 0 (IPX_MFMA_PROF), else null
+#ifdef IPX_DEV
+    int ablate;                                      // dev build: skip phases (timing only, results wrong)
+    long long* prof;                                 // dev build: phase time stamps of block 0 (IPX_MFMA_PROF), else null
+#endif
 };
+// development builds (make EXTRA=-DIPX_DEV) can skip phases and stamp them; the shipped library has neither
+#ifdef IPX_DEV
+#define IPX_PHASE_ON(g, bit) (!((g).ablate & (bit)))
+#else
+#define IPX_PHASE_ON(g, bit) true
+#endif
 struct MTaps { uint8_t kx[32]; uint8_t ky[32]; };
 
 __device__ __forceinline__ const uint8_t* src_row(const MGeom& g, const uint8_t* simg, int y)
@@ -204,8 +212,12 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
     const uint8_t* const r_out = s_out + orow * kPitchO + 16 * occ;
     const unsigned ooff = (unsigned)(orow * (int)g.d_row + 16 * occ);
 
+#ifdef IPX_DEV
     int pslot = 0;
     auto stamp = [&]() { if (g.prof && blockIdx.x == 0 && tid == 0 && pslot < 64) g.prof[pslot++] = (long long)__builtin_readcyclecounter(); };
+#else
+    auto stamp = [] {};
+#endif
     stamp();
     auto do_tile = [&](const Pos& cur, const Pos& fut, u32x4 (&nxt)[NLD]) {
     const bool live = valid(cur);                                 // block-uniform
@@ -217,14 +229,14 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
         lds_barrier();
     }
     stamp();
-    if (valid(fut) && !(g.ablate & 1)) fetch(fut, nxt);
+    if (valid(fut) && IPX_PHASE_ON(g, 1)) fetch(fut, nxt);
     stamp();
     if (!live) return;
 
     // ---- 2. row pass: wave w owns column tile w (16 output columns) of every 16-row tile ----------------------
     // NMT whole 16-row tiles, also when fewer source rows exist (rows >= RY hold stale bytes that only meet zero taps):
     // no branch inside the unrolled loop, so the LDS reads of later tiles overlap the MFMAs and epilogues of earlier ones
-    if (!(g.ablate & 2))
+    if (IPX_PHASE_ON(g, 2))
 #pragma unroll
     for (int mt = 0; mt < NMT; ++mt) {
         v4i acc = {0, 0, 0, 0};
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
 
     stamp();
     // ---- 3. column pass: wave w owns column tile w; result -> staging tile (aliases the source tile) ----------
-    if (!(g.ablate & 4))
+    if (IPX_PHASE_ON(g, 4))
 #pragma unroll
     for (int nt = 0; nt < TY / 16; ++nt) {
         constexpr int c0 = 32768 * 256 + 32768 + 32768;          // rounding and the two +2^15 offsets, via the accumulator
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
 
     stamp();
     // ---- 4. staging tile -> global, 16 bytes per lane, whole 128-byte rows -----------------------------------
-    if (!(g.ablate & 8)) {
+    if (IPX_PHASE_ON(g, 8)) {
         const int x0 = tile_x(cur) * TX, y0 = tile_y(cur) * TY;
         uint8_t* dbase = dst + (int64_t)cur.img * g.d_img + (int64_t)y0 * g.d_row + x0;
         if (g.fast32 && y0 + TY <= g.h && x0 + TX <= g.L) {       // whole tile inside (block-uniform)
@@ -331,7 +343,9 @@ int ipx_sep_mfma(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h,
     // shape = the divisor pair of that number that wastes the fewest tile slots, squarest first
     const uint64_t nt = (uint64_t)n * g.tiles_x * g.tiles_y;
     int nb = 96;
-    if (const char* e = getenv("IPX_MFMA_BLOCKS")) { if (atoi(e) > 0) nb = atoi(e); }                 // dev knob
+#ifdef IPX_DEV
+    if (const char* e = getenv("IPX_MFMA_BLOCKS")) { if (atoi(e) > 0) nb = atoi(e); }
+#endif
     if ((uint64_t)nb * 8 > nt) nb = (int)((nt + 7) / 8);
     g.pw = nb < g.tiles_x ? nb : g.tiles_x;
     g.ph = nb / g.pw > 0 ? nb / g.pw : 1;
@@ -349,10 +363,12 @@ int ipx_sep_mfma(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h,
     if (np > 0x7ffffff0ull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: image too large", fn);
     g.npatches = (unsigned)np;
     MTaps t{};
+#ifdef IPX_DEV
     g.prof = nullptr;
     g.ablate = getenv("IPX_MFMA_ABLATE") ? atoi(getenv("IPX_MFMA_ABLATE")) : 0;
-    const bool prof = getenv("IPX_MFMA_PROF") != nullptr;                    // dev knob: print block 0's phase stamps
+    const bool prof = getenv("IPX_MFMA_PROF") != nullptr;                    // print block 0's phase stamps
     if (prof) { IPX_HIP(hipMalloc((void**)&g.prof, 64 * sizeof(long long))); IPX_HIP(hipMemset(g.prof, 0, 64 * sizeof(long long))); }
+#endif
     for (int i = 0; i < k; ++i) { t.kx[i] = (uint8_t)kx[i]; t.ky[i] = (uint8_t)ky[i]; }
     switch (c) {
         case 1: launch_c<1>(st, src, dst, g, t); break;
@@ -361,6 +377,7 @@ int ipx_sep_mfma(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h,
         default: launch_c<4>(st, src, dst, g, t); break;
     }
     IPX_LAUNCH_CHECK("sep_mfma_kernel");
+#ifdef IPX_DEV
     if (prof) {
         long long hst[64];
         IPX_HIP(hipDeviceSynchronize());
@@ -370,5 +387,6 @@ int ipx_sep_mfma(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h,
         for (int i = 1; i < 64 && hst[i]; ++i) fprintf(stderr, " %lld", hst[i] - hst[0]);
         fprintf(stderr, "\n");
     }
+#endif
     return IPX_OK;
 }

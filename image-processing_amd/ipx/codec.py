@@ -16,23 +16,70 @@ import threading
 import zlib
 
 import numpy as np
-from PIL import Image
+from PIL import Image, ImageOps
 
 
-def _open(img_bytes: bytes) -> Image.Image:
+def _open(img_bytes: bytes, exif_orientation: bool = False) -> Image.Image:
     try:
-        im = Image.open(io.BytesIO(img_bytes))
+        pre = getattr(_TLS, "prefetched", None)
+        if pre is not None and pre.blob is img_bytes:
+            im = pre.fut.result()                                     # decoded ahead by the pool (raises what it raised)
+        else:
+            im = Image.open(io.BytesIO(img_bytes))
+            im.load()
+        if exif_orientation:
+            im = ImageOps.exif_transpose(im)
+        return im
+    except Exception:
+        # cv2.imdecode returns None (it does not raise) for bytes it cannot decode, so server.py:531 always ends in
+        # this fixed text; Pillow's own message would carry a memory address and differ from request to request
+        raise RuntimeError("Cannot decode image to grayscale 8-bit. unknown error")
+
+
+class DecodeAhead:
+    """Decodes a list of uploads on the codec pool ahead of their consumers (/api/process_batch).  `with d.use(i):`
+    makes the calling thread's next _open() of blob i return the image decoded by the pool (or re-raise its error)
+    instead of decoding again; everything else about the dispatch stays as it is."""
+
+    def __init__(self, blobs):
+        self.blobs = blobs
+        self.futures = [_pool().submit(self._decode, b) for b in blobs]
+
+    @staticmethod
+    def _decode(b):
+        im = Image.open(io.BytesIO(b))
         im.load()
         return im
-    except Exception as e:  # same message family as server.py:531
-        raise RuntimeError("Cannot decode image to grayscale 8-bit. " + str(e))
+
+    def use(self, i):
+        return _Prefetched(self.blobs[i], self.futures[i])
 
 
-def decode_unchanged(img_bytes: bytes, order: str = "bgr") -> np.ndarray:
+class _Prefetched:
+    def __init__(self, blob, fut):
+        self.blob, self.fut = blob, fut
+
+    def __enter__(self):
+        _TLS.prefetched = self
+        return self
+
+    def __exit__(self, *a):
+        _TLS.prefetched = None
+        return False
+
+
+_TLS = threading.local()
+
+
+def decode_unchanged(img_bytes: bytes, order: str = "bgr", exif_orientation: bool = False) -> np.ndarray:
     """cv2.imdecode(arr, IMREAD_UNCHANGED) equivalent (server.py:499-501): 2-D gray (uint8/uint16) or
     H x W x {3,4} BGR(A) uint8.  order="rgb" skips the channel reversal (a 25 MB host copy at 4K): the caller then
-    reverses on the GPU, or not at all for per-channel filters."""
-    im = _open(img_bytes)
+    reverses on the GPU, or not at all for per-channel filters.  IMREAD_UNCHANGED ignores the EXIF orientation tag
+    (exif_orientation=False); IMREAD_COLOR applies it (decode_color).
+    Known divergence: a 16-bit COLOUR file reaches the reference as uint16 BGR (gray conversion on 16 bits, then
+    >> 8, server.py:517-523); Pillow hands over 8-bit RGB, so the 8-bit gray formula runs on truncated samples and a
+    pixel can differ by one."""
+    im = _open(img_bytes, exif_orientation)
     if im.mode in ("L",):
         return np.array(im, dtype=np.uint8)
     if im.mode in ("I;16", "I;16B", "I;16L", "I"):
@@ -47,9 +94,10 @@ def decode_unchanged(img_bytes: bytes, order: str = "bgr") -> np.ndarray:
 
 
 def decode_color(img_bytes: bytes, order: str = "bgr"):
-    """cv2.imdecode(arr, IMREAD_COLOR) equivalent (server.py:252): always H x W x 3 BGR uint8, or None."""
+    """cv2.imdecode(arr, IMREAD_COLOR) equivalent (server.py:252): always H x W x 3 BGR uint8, or None.  Unlike
+    IMREAD_UNCHANGED this flag honours the EXIF orientation of a JPEG (a phone photo comes out upright)."""
     try:
-        a = decode_unchanged(img_bytes, order)
+        a = decode_unchanged(img_bytes, order, exif_orientation=True)
     except RuntimeError:
         return None
     if a.dtype == np.uint16:

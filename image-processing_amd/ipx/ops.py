@@ -81,10 +81,13 @@ def _halo(t: Optional[torch.Tensor], src: _Img, r: int, name: str):
     hv = _Img(t, name)
     if hv.h != r or hv.w != src.w or hv.c != src.c:
         raise ValueError(f"{name}: expected {r} x {src.w} x {src.c}, got {hv.h} x {hv.w} x {hv.c}")
+    if hv.t.device != src.t.device:
+        raise ValueError(f"{name}: on {hv.t.device}, the image is on {src.t.device}")
     if hv.h > 1 and hv.row != src.row:
-        hv = _Img(t.contiguous(), name)
-        if hv.row != src.row:
-            raise ValueError(f"{name}: row stride {hv.row} differs from the image's {src.row}")
+        # the library reads halo rows with the SOURCE's row stride (include/ipx.h): re-lay them out that way
+        buf = torch.empty((r, src.row), dtype=torch.uint8, device=src.t.device)
+        buf[:, :src.w * src.c].view(r, src.w, src.c).copy_(hv.t[0])
+        return buf, buf.data_ptr()
     return hv, hv.ptr
 
 

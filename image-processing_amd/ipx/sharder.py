@@ -121,6 +121,14 @@ class RowPartition:
             _lib.load()
             ops = _ops
         self.ops = ops
+        # gloo carries host tensors only: device tensors are staged through the host then (rehearsals on one GPU, CPU
+        # tests); RCCL ("nccl") moves device memory directly over xGMI
+        self.host_staging = world > 1 and dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+    def _wire(self, t):
+        """The tensor as it goes on the wire: contiguous, on the host when the backend cannot carry device memory."""
+        t = t.contiguous()
+        return t.cpu() if (self.host_staging and t.is_cuda) else t
 
     def rows(self) -> slice:
         return slice(self.y0, self.y1)
@@ -135,17 +143,21 @@ class RowPartition:
         if self.min_rows < r:
             raise ValueError(f"row shards of {self.min_rows} rows are shorter than the halo radius {r}")
         up, down = self.rank - 1, self.rank + 1
-        top = torch.empty_like(local[:r]) if up >= 0 else None
-        bot = torch.empty_like(local[:r]) if down < self.world else None
+        first, last = self._wire(local[:r]), self._wire(local[-r:])
+        top = torch.empty_like(first) if up >= 0 else None
+        bot = torch.empty_like(last) if down < self.world else None
         ops_ = []
         if up >= 0:
-            ops_.append(dist.P2POp(dist.isend, local[:r].contiguous(), up, group=self.group))
+            ops_.append(dist.P2POp(dist.isend, first, up, group=self.group))
             ops_.append(dist.P2POp(dist.irecv, top, up, group=self.group))
         if down < self.world:
-            ops_.append(dist.P2POp(dist.isend, local[-r:].contiguous(), down, group=self.group))
+            ops_.append(dist.P2POp(dist.isend, last, down, group=self.group))
             ops_.append(dist.P2POp(dist.irecv, bot, down, group=self.group))
         for w in dist.batch_isend_irecv(ops_):
             w.wait()
+        if self.host_staging and local.is_cuda:
+            top = top.to(local.device) if top is not None else None
+            bot = bot.to(local.device) if bot is not None else None
         return top, bot
 
     def conv3(self, local, name: str):
@@ -161,7 +173,9 @@ class RowPartition:
     def global_hist(self, local):
         h = self.ops.hist(local).reshape(256).contiguous()
         if self.world > 1:
-            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            w = self._wire(h)
+            self.dist.all_reduce(w, op=self.dist.ReduceOp.SUM, group=self.group)
+            h = w.to(h.device) if w is not h else h
         return h
 
     def equalize_hist(self, local):

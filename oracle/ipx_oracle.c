@@ -126,9 +126,13 @@ int orc_gauss_kernel_q8(int k, double sigma, uint16_t* out)
     if (sigma <= 0 && k <= 9) {
         for (int i = 0; i < k; ++i) kf[i] = small_tab[k / 2][i];
     } else {
-        double sg = sigma > 0 ? sigma : 0.15 * k + 0.35, sum = 0;
-        for (int i = 0; i < k; ++i) { double x = i - (k - 1) * 0.5; kf[i] = exp(-0.5 * x * x / (sg * sg)); sum += kf[i]; }
-        for (int i = 0; i < k; ++i) kf[i] /= sum;
+        /* getGaussianKernelBitExact's order: sigma by one fused multiply-add, integer abscissa x = 2i-(k-1) with scale
+           -0.125/sigma^2, first half summed, sum = 2*half + 1, taps multiplied by 1/sum */
+        double sg = sigma > 0 ? sigma : fma((double)k, 0.15, 0.35), scale2 = -0.125 / (sg * sg), half = 0;
+        for (int i = 0, x = 1 - k; i < k / 2; ++i, x += 2) { kf[i] = exp((double)(x * x) * scale2); half += kf[i]; }
+        double mul1 = 1.0 / (half * 2.0 + 1.0);
+        for (int i = 0; i < k / 2; ++i) { kf[i] *= mul1; kf[k - 1 - i] = kf[i]; }
+        kf[k / 2] = mul1;
     }
     double err = 0; int acc = 0;
     for (int i = 0; i < k / 2; ++i) {

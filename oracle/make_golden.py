@@ -104,8 +104,8 @@ def main():
 
     def post(img, mode, **form):
         data = {"mode": mode, **{k: str(v) for k, v in form.items()}}
-        if img is not None:
-            data["file"] = (io.BytesIO(_png(img)), "x.png")
+        if img is not None:                               # a 1-D array is sent as raw file bytes (not an image)
+            data["file"] = (io.BytesIO(img.tobytes() if img.ndim == 1 else _png(img)), "x.png")
         if mode is None:
             data.pop("mode")
         r = client.post("/api/process", data=data, content_type="multipart/form-data")
@@ -185,6 +185,21 @@ def main():
     arrays["in_saltpepper"] = sp
     for key, kern in (("rand", 5), ("lee", 4), ("narrow", 7), ("const", 3), ("saltpepper", 5), ("lowmax", 40), ("ramp", 9)):
         case(f"denoise_lee_{key}_{kern}", key, "denoise_manual", method="lee", kernel=kern)
+
+    # an upload that is not an image: cv2.imdecode returns None for every flag, ensure_gray_uint8_from_bytes raises
+    # "unknown error" (server.py:531) and the blanket handler answers 500 -- BEFORE any parameter check of the gray
+    # branch (server.py:360 decodes first), also for histogram_eq / sharpening / denoise_manual / median
+    imgs["garbage"] = np.frombuffer(b"this is not an image file, just 50 bytes of plain text..", np.uint8).copy()
+    arrays["in_garbage"] = imgs["garbage"]
+    case("garbage_gray8", "garbage", "gray8")
+    case("garbage_gamma_missing_param", "garbage", "gamma")
+    case("garbage_gamma", "garbage", "gamma", gamma=0.5)
+    case("garbage_piecewise_missing_params", "garbage", "piecewise", r1=1)
+    case("garbage_histogram_eq", "garbage", "histogram_eq")
+    case("garbage_sharpening", "garbage", "sharpening")
+    case("garbage_denoise_manual", "garbage", "denoise_manual", method="lee")
+    case("garbage_median_nlm", "garbage", "median", nlm=1)
+    case("garbage_pca", "garbage", "pca")                     # decided before any decode: still 400
 
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, "server_numpy_ops.npz"), **arrays)

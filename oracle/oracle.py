@@ -23,6 +23,8 @@ Every function cites the reference line it restates.
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 # --------------------------------------------------------------------------
@@ -222,17 +224,31 @@ _SMALL_GAUSS = {1: [1.0], 3: [0.25, 0.5, 0.25], 5: [0.0625, 0.25, 0.375, 0.25, 0
 
 
 def gauss_kernel_float(k: int, sigma: float = 0.0) -> np.ndarray:
-    """OpenCV smooth.dispatch.cpp getGaussianKernelBitExact(): fixed tables for
-    sigma<=0 and k in {1,3,5,7,9}; else sigma = 0.15*k + 0.35 (== 0.3*((k-1)/2-1)+0.8),
-    taps exp(-x^2/(2 sigma^2)) normalised to sum 1.  OpenCV evaluates this in
-    softfloat; float64 here (differences are far below the Q0.8 quantum)."""
+    """OpenCV smooth.dispatch.cpp getGaussianKernelBitExact(), operation by operation: fixed tables for sigma<=0 and
+    k in {1,3,5,7,9}; else sigma = mulAdd(k, 0.15, 0.35) (ONE rounding), scale2X = -0.125 / sigma^2 with the integer
+    abscissa x = 2 i - (k - 1), taps t_i = exp(x*x * scale2X) for the FIRST half only, sum = 2 * sum(t_i) + 1 (the centre
+    tap is exp(0) = 1), every tap multiplied by mul1 = 1 / sum.  OpenCV evaluates exp in softfloat, float64 libm here;
+    tests/test_oracle_golden.py proves with 60-digit arithmetic that no Q0.8 tap of k <= 255 is near enough to a
+    rounding tie for an ulp of difference to show."""
     assert k >= 1 and k % 2 == 1
     if sigma <= 0 and k in _SMALL_GAUSS:
         return np.array(_SMALL_GAUSS[k], np.float64)
-    sg = sigma if sigma > 0 else 0.15 * k + 0.35
-    x = np.arange(k, dtype=np.float64) - (k - 1) * 0.5
-    t = np.exp(-0.5 * x * x / (sg * sg))
-    return t / t.sum()
+    from fractions import Fraction
+    # a fused multiply-add is the exact rational result rounded once
+    sg = float(sigma) if sigma > 0 else float(Fraction(k) * Fraction(0.15) + Fraction(0.35))
+    scale2 = -0.125 / (sg * sg)
+    n2 = (k - 1) // 2
+    vals = [math.exp(float((2 * i - (k - 1)) ** 2) * scale2) for i in range(n2)]
+    tot = 0.0
+    for t in vals:
+        tot += t
+    tot = tot * 2.0 + 1.0
+    mul1 = 1.0 / tot
+    out = np.empty(k, np.float64)
+    for i in range(n2):
+        out[i] = out[k - 1 - i] = vals[i] * mul1
+    out[n2] = 1.0 * mul1
+    return out
 
 
 def gauss_kernel_q8(k: int, sigma: float = 0.0) -> np.ndarray:

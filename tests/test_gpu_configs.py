@@ -1,0 +1,169 @@
+"""BASELINE.json configs[2], configs[3], configs[4] at their REAL shapes on one MI355X, through the C ABI, against the
+C / numpy oracle (exact equality; all of it is integer / table arithmetic).
+
+configs[2]: batch of 1080 x 1920 RGB frames, full filter pipeline (server.py:360-388, 443-467, 245-246, 263-277, 428)
+configs[3]: one 4320 x 7680 RGB frame, separable Gaussian k = 15 and 31 (server.py:428 arithmetic per channel)
+configs[4]: one 32768 x 32768 gray image, 8 row partitions of 4096 rows: hist-eq (server.py:246) + 3x3 convs
+Parity vs real OpenCV is unpinned (cv2 absent); the numpy branches are pinned by tests/golden.
+"""
+import numpy as np
+import pytest
+import torch
+
+import coracle as CO
+import oracle as O
+import ipx.luts as luts
+import ipx.ops as ops
+import ipx.pipelines as P
+from ipx.sharder import BatchSharder
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(n, h, w, seed):
+    """n synthetic BGR frames with different brightness ranges (so that every image has its own log / equalize table)."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, h, w, 3), np.uint8)
+    for i in range(n):
+        hi = 256 if i % 3 == 0 else 120 + 15 * (i % 8)            # the log table depends on the image maximum
+        out[i] = rng.integers(i % 5, hi, (h, w, 3), dtype=np.uint8)
+    return out
+
+
+def _oracle_full_pipeline(bgr):
+    """The same nine outputs for ONE frame from the oracle (C restatement where it exists, numpy otherwise)."""
+    gray = CO.bgr2gray_u8(bgr)
+    return {"gray": gray, "histogram_eq": CO.equalize_hist_u8(gray),
+            "negative": O.negative_u8(gray), "threshold": O.threshold_u8(gray, 128), "gamma": O.gamma_u8(gray, 0.6),
+            "log": O.log_u8(gray, 2.0), "piecewise": O.piecewise_u8(gray, 70, 10, 180, 245),
+            "sharpening": CO.laplacian_sharpen_u8(bgr), "gaussian5": CO.gaussian_blur_u8(bgr, 5)}
+
+
+def test_configs2_full_pipeline_1080p_batch(dev):
+    n, h, w = 8, 1080, 1920
+    frames = _frames(n, h, w, 1002)
+    got = P.full_pipeline(ops, torch.from_numpy(frames).to(dev))
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    tabs = set()
+    for i in range(n):
+        want = _oracle_full_pipeline(frames[i])
+        for name, ref in want.items():
+            g = got[name][i]
+            np.testing.assert_array_equal(g[..., 0] if ref.ndim == 2 else g, ref, err_msg=f"frame {i} {name}")
+        tabs.add(luts.log(2.0, O.hist_u8(want["gray"])).tobytes())
+    assert len(tabs) >= 4                                       # the batch really needs one log table per image
+
+
+def test_configs2_batch_sharder_keeps_input_order(dev):
+    """16 frames through BatchSharder.map (image i -> worker i mod G; two workers on the one GPU here): results come
+    back in input order and equal the oracle's."""
+    n, h, w = 16, 1080, 1920
+    frames = _frames(n, h, w, 77)
+    sh = BatchSharder([dev, dev])
+
+    def fn(o, t):
+        r = P.full_pipeline(o, t[None])
+        return r["histogram_eq"][0, :, :, 0], r["log"][0, :, :, 0], r["sharpening"][0]
+    res = sh.map(list(frames), fn)
+    for i in (0, 1, 2, 7, 8, 15):
+        gray = CO.bgr2gray_u8(frames[i])
+        np.testing.assert_array_equal(res[i][0], CO.equalize_hist_u8(gray), err_msg=f"frame {i} eq")
+        np.testing.assert_array_equal(res[i][1], O.log_u8(gray, 2.0), err_msg=f"frame {i} log")
+        np.testing.assert_array_equal(res[i][2], CO.laplacian_sharpen_u8(frames[i]), err_msg=f"frame {i} sharpen")
+    # every frame is distinct, so an order mix-up cannot go unnoticed on the frames not checked against the oracle
+    sums = [int(r[0].astype(np.int64).sum()) for r in res]
+    assert len(set(sums)) == n
+
+
+@pytest.mark.parametrize("k", [15, 31])
+def test_configs3_8k_rgb_large_gaussian(dev, k):
+    h, w, r = 4320, 7680, k // 2
+    g = torch.Generator(device="cpu").manual_seed(8000 + k)
+    img = torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, generator=g)
+    got = ops.gaussian_blur(img.to(dev), k).cpu().numpy()
+    a = img.numpy()
+    # row bands (full width: left and right borders included): top, bottom, interior tile seams (64-row tiles)
+    for y0, y1 in ((0, 96), (h - 96, h), (2048 - 40, 2048 + 40), (1000, 1080)):
+        b0, b1 = max(0, y0 - r), min(h, y1 + r)
+        ref = CO.gaussian_blur_u8(a[b0:b1], k)                 # the band's own REFLECT_101 is right only at the image edge
+        np.testing.assert_array_equal(got[y0:y1], ref[y0 - b0:y0 - b0 + (y1 - y0)], err_msg=f"k={k} rows {y0}:{y1}")
+    # column bands over the full height: 128-byte tile seams in x and both side borders
+    for x0, x1 in ((0, 64), (w - 64, w), (3829, 3861)):
+        c0, c1 = max(0, x0 - r), min(w, x1 + r)
+        ref = CO.gaussian_blur_u8(np.ascontiguousarray(a[:, c0:c1]), k)
+        np.testing.assert_array_equal(got[:, x0:x1], ref[:, x0 - c0:x0 - c0 + (x1 - x0)], err_msg=f"k={k} cols {x0}:{x1}")
+    # the numpy restatement agrees with the C one on a corner crop (two independent restatements)
+    np.testing.assert_array_equal(got[:40, :50], O.gaussian_blur_u8(a[:40 + r, :50 + r], k)[:40, :50])
+
+
+def test_configs4_32k_gray_row_partitions(dev):
+    H = W = 32768
+    parts, rows = 8, 4096
+    g = torch.Generator(device=dev).manual_seed(32768)
+    img = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    for p in range(parts):                                      # generated on the device, 128 MiB slabs; low-contrast slabs
+        lo, hi = (0, 256) if p % 2 == 0 else (30 + p, 200 + p)
+        img[p * rows:(p + 1) * rows] = torch.randint(lo, hi, (rows, W), dtype=torch.uint8, device=dev, generator=g)
+    eq, hist, lut = ops.equalize_hist(img, return_aux=True)
+    assert int(hist.to(torch.int64).sum()) == H * W == 1 << 30
+    # per-partition histograms (what each of 8 GPUs computes) equal torch's own count and sum to the global one
+    hsum = torch.zeros(256, dtype=torch.int64, device=dev)
+    for p in range(parts):
+        hp = ops.hist(img[p * rows:(p + 1) * rows]).to(torch.int64)
+        ref = torch.zeros(256, dtype=torch.int64, device=dev)
+        for q in range(4):                                      # bincount in 32 MiB pieces (int64 temporaries)
+            ref += torch.bincount(img[p * rows + q * 1024:p * rows + (q + 1) * 1024].flatten().to(torch.int64), minlength=256)
+        assert torch.equal(hp, ref), f"partition {p} histogram"
+        hsum += hp
+    assert torch.equal(hsum, hist[0].to(torch.int64))
+    hist_np = hsum.cpu().numpy()
+    want_lut = O.equalize_lut_from_hist(hist_np)
+    np.testing.assert_array_equal(lut[0].cpu().numpy(), want_lut)
+    np.testing.assert_array_equal(CO.equalize_lut_from_hist(hist_np.astype(np.uint32)), want_lut)
+    lut_from_sum = ops.equalize_lut(hsum.to(torch.int32))       # the table every rank builds after the all-reduce
+    whole = {"box3": ops.box3(img), "sobel": ops.sobel(img)}
+    for p in range(parts):
+        y0, y1 = p * rows, (p + 1) * rows
+        part = img[y0:y1]
+        top = img[y0 - 1:y0] if p > 0 else None
+        bot = img[y1:y1 + 1] if p < parts - 1 else None
+        assert torch.equal(ops.apply_lut_dev(part, lut_from_sum), eq[y0:y1]), f"partition {p} equalize"
+        for name in ("box3", "sobel"):
+            assert torch.equal(getattr(ops, name)(part, top_halo=top, bottom_halo=bot), whole[name][y0:y1]), f"partition {p} {name}"
+    # oracle on row bands across two partition seams, the image top and the image bottom (full 32768-pixel rows)
+    for y0, y1 in ((4096 - 8, 4096 + 8), (7 * 4096 - 8, 7 * 4096 + 8), (0, 12), (H - 12, H)):
+        b0, b1 = max(0, y0 - 1), min(H, y1 + 1)
+        band = img[b0:b1].cpu().numpy()
+        sl = slice(y0 - b0, y0 - b0 + (y1 - y0))
+        np.testing.assert_array_equal(whole["box3"][y0:y1].cpu().numpy(), CO.box3_u8(band)[sl], err_msg=f"box3 rows {y0}:{y1}")
+        np.testing.assert_array_equal(whole["sobel"][y0:y1].cpu().numpy(), CO.sobel_u8(band)[sl], err_msg=f"sobel rows {y0}:{y1}")
+        np.testing.assert_array_equal(eq[y0:y1].cpu().numpy(), want_lut[img[y0:y1].cpu().numpy()], err_msg=f"equalize rows {y0}:{y1}")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_partition_ranks_run_the_hip_library(dev, world):
+    """SURVEY.md section 8(e) case 2 rehearsed on ONE GPU: `world` fresh child processes (started, not exec'd), each
+    owning a block of rows of one image on cuda:0, exchange halo rows / all-reduce the histogram through
+    torch.distributed (gloo; RowPartition stages device tensors through the host) and run libipx on their rows:
+    conv3, Gaussian 5 / 7 / 15 / 31, equalize_hist and log_transform equal the single-process whole-image result."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "rowpart_worker.py")
+    procs = [subprocess.Popen([sys.executable, "-u", worker, str(r), str(world), str(port)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=200)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and o.strip().endswith("ok"), f"rank {r}:\n{o}"

@@ -26,8 +26,8 @@ def post(client, img, mode, **form):
     data = {k: str(v) for k, v in form.items()}
     if mode is not None:
         data["mode"] = mode
-    if img is not None:
-        data["file"] = (io.BytesIO(png(img)), "x.png")
+    if img is not None:                                   # a 1-D array is raw file bytes (the "garbage" golden input)
+        data["file"] = (io.BytesIO(img.tobytes() if img.ndim == 1 else png(img)), "x.png")
     r = client.post("/api/process", data=data, content_type="multipart/form-data")
     return r.status_code, r.get_json()
 
@@ -106,7 +106,7 @@ def test_out_of_scope_modes_say_so(client):
     assert st == 501
     r = client.post("/api/process", data={"mode": "gray8", "file": (io.BytesIO(b"not an image"), "x.png")},
                     content_type="multipart/form-data")
-    assert r.status_code == 500 and "Cannot decode image" in r.get_json()["error"]
+    assert r.status_code == 500 and r.get_json()["error"] == "Cannot decode image to grayscale 8-bit. unknown error"
 
 
 def test_median_modes_contract(client):
@@ -147,7 +147,8 @@ def test_batch_endpoint(client):
         np.testing.assert_array_equal(codec.from_data_url_png(res["dataURL"]), O.laplacian_sharpen_u8(a[:, :, ::-1]))
     data = {"mode": "gamma", "file": [(io.BytesIO(png(imgs[0])), "a.png"), (io.BytesIO(b"junk"), "b.png")]}
     js = client.post("/api/process_batch", data=data, content_type="multipart/form-data").get_json()
-    assert [x["status"] for x in js["results"]] == [400, 400]            # gamma missing -> 400 each (server.py:365)
+    assert [x["status"] for x in js["results"]] == [400, 500]            # gamma missing -> 400 (server.py:365); the junk file
+                                                                         # fails its decode first (server.py:360) -> 500
     data = {"mode": "negative", "file": [(io.BytesIO(png(imgs[0])), "a.png"), (io.BytesIO(b"junk"), "b.png")]}
     js = client.post("/api/process_batch", data=data, content_type="multipart/form-data").get_json()
     assert [x["status"] for x in js["results"]] == [200, 500] and "Cannot decode" in js["results"][1]["error"]
@@ -181,6 +182,26 @@ def test_codec_alpha_16bit_palette():
     np.testing.assert_array_equal(app_mod.ensure_gray_uint8(OracleBackend(), png(rgba)), O.bgr2gray_u8(rgba[..., [2, 1, 0, 3]]))
     bgr = rng.integers(0, 256, (5, 6, 3), dtype=np.uint8)
     np.testing.assert_array_equal(codec.from_data_url_png(codec.to_data_url_png(bgr)), bgr)
+
+
+def test_decode_color_applies_exif_orientation_decode_unchanged_does_not():
+    """cv2.IMREAD_COLOR (mode=sharpening, server.py:252) honours a JPEG's EXIF orientation; IMREAD_UNCHANGED (every
+    gray-path mode, server.py:499) ignores it.  OpenCV documents both; parity with the real decoder is unpinned."""
+    yy, xx = np.mgrid[0:24, 0:40]
+    rgb = np.stack([(xx * 6) % 256, (yy * 10) % 256, (xx + yy) * 3 % 256], -1).astype(np.uint8)
+    exif = Image.Exif()
+    exif[0x0112] = 6                                                  # rotate 90 degrees clockwise to display
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, format="JPEG", quality=95, exif=exif)
+    plain = io.BytesIO()
+    Image.fromarray(rgb).save(plain, format="JPEG", quality=95)
+    base = codec.decode_unchanged(plain.getvalue(), "rgb")
+    assert codec.decode_unchanged(buf.getvalue(), "rgb").shape == (24, 40, 3)           # tag ignored
+    np.testing.assert_array_equal(codec.decode_unchanged(buf.getvalue(), "rgb"), base)
+    col = codec.decode_color(buf.getvalue(), "rgb")
+    assert col.shape == (40, 24, 3)                                                   # tag applied
+    np.testing.assert_array_equal(col, np.rot90(base, k=-1))
+    np.testing.assert_array_equal(codec.decode_color(plain.getvalue(), "rgb"), base)
 
 
 def test_batch_sharder_order_and_round_robin():

@@ -80,7 +80,7 @@ def test_denoise_stats_match_real_server(golden):
     g, meta = golden
     n = 0
     for c in meta["cases"]:
-        if c["mode"] != "denoise_manual":
+        if c["mode"] != "denoise_manual" or c["status"] != 200:
             continue
         img, ref = g["in_" + c["input"]], c["params"]["histogram"]
         s = O.denoise_stats(img, "lee")
@@ -211,3 +211,41 @@ def test_numpy_reduction_order_is_what_the_stats_kernel_assumes():
         assert O.pairwise_sum_f32(b * b) == np.add.reduce(b * b), n
     big = rng.integers(0, 256, 1080 * 1920, dtype=np.uint8).astype(np.float32)     # sums beyond 2^24: rounding order matters
     assert O.pairwise_sum_f32(big) == np.add.reduce(big) == np.float32(np.mean(big) * 0 + np.add.reduce(big))
+
+
+def test_gauss_taps_are_far_from_rounding_ties_for_every_k():
+    """Pins the Q0.8 tap tables WITHOUT OpenCV: for k = 11..255 the taps are recomputed in 60-digit
+    decimal arithmetic (exact sigma = 0.15 k + 0.35, exp, normalisation, error diffusion) and every value handed to
+    cvRound, f[i] * 256 + err, must be farther from a .5 tie than any float64 / softfloat evaluation error could reach
+    (margin 1e-9 against an error below 1e-12).  Then the order of float operations -- fused or unfused sigma, full or
+    half sum, divide or multiply by the reciprocal, libm or softfloat exp -- cannot change a tap, and the float64
+    restatements (numpy, C, and the library's host helper) must reproduce the high-precision table."""
+    import ctypes as C
+    from decimal import Decimal, getcontext
+    import ipx._lib as L
+    getcontext().prec = 60
+    lib = L.load()
+    worst = Decimal(1)
+    for k in range(11, 256, 2):
+        sg = Decimal(0.15) * k + Decimal(0.35)                  # the double constants OpenCV holds, combined exactly
+        scale2 = Decimal(-0.125) / (sg * sg)
+        n2 = (k - 1) // 2
+        vals = [(Decimal((2 * i - (k - 1)) ** 2) * scale2).exp() for i in range(n2)]
+        tot = sum(vals) * 2 + 1
+        err = Decimal(0)
+        taps = [0] * k
+        for i in range(n2):
+            adj = vals[i] / tot * 256 + err
+            v0 = int(adj.to_integral_value(rounding="ROUND_HALF_EVEN"))
+            margin = abs(abs(adj - v0) - Decimal("0.5"))
+            worst = min(worst, margin)
+            err = adj - v0
+            taps[i] = taps[k - 1 - i] = v0
+        taps[n2] = 256 - 2 * sum(taps[:n2])
+        assert worst > Decimal("1e-9"), (k, worst)
+        assert O.gauss_kernel_q8(k).tolist() == taps, k
+        assert CO.gauss_kernel_q8(k).tolist() == taps, k
+        out = np.zeros(k, np.uint16)
+        assert lib.ipx_gauss_kernel_q8(k, C.c_double(0.0), out.ctypes.data) == 0
+        assert out.tolist() == taps, k
+        assert min(taps) >= 0 and sum(taps) == 256
