@@ -7,9 +7,12 @@
 // packed 16-bit "field pairs" (v_perm_b32) and does the horizontal part of the filter with packed 16-bit VALU ops;
 // the vertical window of those row features lives in registers.  Loads run U rows ahead of the arithmetic.
 // Every input byte is fetched from HBM once (plus r halo rows per segment); nothing is staged twice.
-// The lanes of the main region never touch the left/right image border: the first 16 bytes of every row and the
-// ragged tail behind the last full lane are computed by "border" blocks appended to the same launch with plain
-// per-byte code (REFLECT_101 in pixel space).  Tiny images are all border.
+// A row of L bytes is cut into ceil(L / 16) lanes; the last lane is shifted left so that it ends at the row's last byte
+// (and the one before it so that its halo stays inside the row): lanes may overlap there and store the same bytes
+// twice.  The first and last lane build their missing halo bytes in registers (REFLECT_101 in pixel space,
+// ipx_fields.h fix_edges), so the whole image is computed by the vector lanes -- no separate pass over border bytes,
+// which used to be two thirds of the waves of a 4K gray launch and its tail.  Only images whose rows are shorter than
+// 32 + halo bytes are computed per byte ("border" blocks: one byte per thread, plain code).
 // Neighbouring strips are consecutive work items and the block->item map is XCD-aware so that they share an L2.
 // 9..31 taps: ipx_sepmfma.hip (both passes as banded int8 matrix products on the MFMA units; taps above 127 fall back
 // to ipx_sepbig.hip, a row-pass kernel + column-pass kernel around a Q8.8 scratch image).  Anything larger
@@ -28,16 +31,20 @@ int ipx_sep_mfma(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h,
 namespace {
 
 constexpr int kMaxWavesPerBlock = 16;
+#ifndef IPX_CONV3_U
+#define IPX_CONV3_U 4
+#endif
+constexpr int kConv3U = IPX_CONV3_U;
 
 
 struct ConvGeom {
     int h, w, L;                       // rows, pixels per row, bytes per row
     int64_t s_row, s_img, d_row, d_img;
-    int nlanes;                        // 16-byte lanes of the main region: bytes [16, 16 + 16*nlanes)
+    int nlanes;                        // 16-byte lanes per row (0: rows too short, the whole image goes per byte)
     int lanes_per_strip, nstrips, seg_rows, nsegs;
     int wpb, blocks_per_seg;           // waves per block, blocks per (image, segment)
-    unsigned main_blocks;              // blocks [0, main_blocks) walk strips, the rest do border bytes
-    int nb;                            // border bytes per row: [0,16) and [16 + 16*nlanes, L)  (or all of L)
+    unsigned main_blocks;              // blocks [0, main_blocks) walk strips, the rest compute single bytes
+    int nb;                            // bytes per row computed singly: 0, or all of L for short rows
     unsigned border_total;             // n * h * nb
     const uint8_t* top;                // r halo rows above row 0 (row -r first), or null = reflect
     const uint8_t* bot;                // r halo rows below row h-1, or null = reflect
@@ -168,7 +175,7 @@ __device__ __forceinline__ bool border_item(const ConvGeom& g, unsigned bblock, 
     const unsigned j = t % (unsigned)g.nb, rest = t / (unsigned)g.nb;
     y = (int)(rest % (unsigned)g.h);
     img = rest / (unsigned)g.h;
-    b = g.nlanes > 0 ? ((int)j < 16 ? (int)j : 16 * g.nlanes + (int)j) : (int)j;
+    b = (int)j;
     return true;
 }
 
@@ -190,6 +197,16 @@ __device__ __forceinline__ bool wave_item(const ConvGeom& g, unsigned& img, int&
     return true;
 }
 
+// First row byte of 16-byte lane gl (0 <= gl < nlanes): 16 gl, except that the last lane ends at the row's last byte and
+// the one before it ends where the last one starts at the latest (its right halo then lies inside the row).
+__device__ __forceinline__ int lane_b0(const ConvGeom& g, int gl)
+{
+    int b0 = 16 * gl;
+    if (gl == g.nlanes - 1) b0 = g.L - 16;
+    else if (gl == g.nlanes - 2 && b0 > g.L - 32) b0 = g.L - 32;
+    return b0;
+}
+
 template <int OP, int C>
 __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void conv3_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                          ConvGeom g)
@@ -206,40 +223,59 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void conv3_kernel(const uin
     }
     unsigned img; int y0, y1, lane0;
     if (!wave_item(g, img, y0, y1, lane0)) return;
-    const int gl = lane0 + (int)(threadIdx.x & 63u);         // 16-byte lane of the row; lane 0 is border
-    if (gl == 0 || gl > g.nlanes) return;
-    const int b0 = 16 * gl;
+    const int gl = lane0 + (int)(threadIdx.x & 63u);         // 16-byte lane of the row
+    if (gl >= g.nlanes) return;
+    const int b0 = lane_b0(g, gl);
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     typedef Win<C, 1> W1;
     typedef Conv3<OP, C> Op;
-    constexpr int U = 4;                                     // rows per step; loads run one step ahead
+    constexpr int U = kConv3U;                               // rows per step; loads run one step ahead
 
     // (Walking odd segments upwards so that neighbours meet at their shared halo rows was tried: no gain, removed.)
     const int nrows = y1 - y0;
     constexpr int dir = 1;
     const int ys = y0;                                       // first output row
     auto row = [&](int t) {                                  // t-th source row of the walk, t = 0 .. nrows + 1
+#if IPX_ABLATE & 2          // dev ablation: clamped rows instead of halo rows / REFLECT_101 (timing only)
+        int yy = ys + (t <= nrows + 1 ? t : nrows + 1) - 1;
+        yy = yy < 0 ? 0 : yy > g.h - 1 ? g.h - 1 : yy;
+        return simg + (int64_t)yy * g.s_row;
+#else
         return row_ptr(g, simg, ys + dir * ((t <= nrows + 1 ? t : nrows + 1) - 1), 1);
+#endif
     };
     typename Op::Feat fa, fb;
     {
         W1 wa, wb;
-        load_win<C, 1>(wa, row(0), b0);
-        load_win<C, 1>(wb, row(1), b0);
+        load_win<C, 1>(wa, row(0), b0, g.L);
+        load_win<C, 1>(wb, row(1), b0, g.L);
+        fix_edges<C, 1>(wa, first, last);
+        fix_edges<C, 1>(wb, first, last);
         Op::feat(fa, wa);
         Op::feat(fb, wb);
     }
     W1 nx[U];
 #pragma unroll
-    for (int j = 0; j < U; ++j) load_win<C, 1>(nx[j], row(2 + j), b0);
+    for (int j = 0; j < U; ++j) load_win<C, 1>(nx[j], row(2 + j), b0, g.L);
     for (int i = 0; i < nrows; i += U) {
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             typename Op::Feat fc;
+            fix_edges<C, 1>(nx[j], first, last);
             Op::feat(fc, nx[j]);
-            load_win<C, 1>(nx[j], row(i + U + 2 + j), b0);   // the slot is free: refill it with the row U steps further on
+#if IPX_ABLATE & 4          // dev ablation: no arithmetic, the window's own 16 bytes are stored (timing only)
+            u32x4 ctr;
+            __builtin_memcpy(&ctr, &nx[j].w[W1::HD], 16);
+            ctr[0] ^= nx[j].w[0] ^ nx[j].w[W1::HD + 4];
+#endif
+            load_win<C, 1>(nx[j], row(i + U + 2 + j), b0, g.L);    // the slot is free: refill it with the row U steps further on
+#if IPX_ABLATE & 4
+            if (i + j < nrows) st16_nt(dimg + (int64_t)(ys + dir * (i + j)) * g.d_row + b0, ctr);
+#else
             if (i + j < nrows) st16_nt(dimg + (int64_t)(ys + dir * (i + j)) * g.d_row + b0, Op::out(fa, fb, fc));
+#endif
             fa = fb;
             fb = fc;
         }
@@ -330,9 +366,10 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
     }
     unsigned img; int y0, y1, lane0;
     if (!wave_item(g, img, y0, y1, lane0)) return;
-    const int gl = lane0 + (int)(threadIdx.x & 63u);         // 16-byte lane of the row; lane 0 is border
-    if (gl == 0 || gl > g.nlanes) return;
-    const int b0 = 16 * gl;
+    const int gl = lane0 + (int)(threadIdx.x & 63u);         // 16-byte lane of the row
+    if (gl >= g.nlanes) return;
+    const int b0 = lane_b0(g, gl);
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     typedef Win<C, R> WR;
@@ -350,8 +387,10 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
 #pragma unroll
     for (int p = 0; p < NP - 1; ++p) {                       // prologue: pairs 0 .. NP-2
         WR wa, wb;
-        load_win<C, R>(wa, row(2 * p), b0);
-        load_win<C, R>(wb, row(2 * p + 1), b0);
+        load_win<C, R>(wa, row(2 * p), b0, g.L);
+        load_win<C, R>(wb, row(2 * p + 1), b0, g.L);
+        fix_edges<C, R>(wa, first, last);
+        fix_edges<C, R>(wb, first, last);
         make_pair<C, K>(pl[p], ph[p], wa, wb, t);
     }
     constexpr int DP = 1;                                     // loads run DP row pairs ahead (DP divides NP: static slots).
@@ -359,14 +398,16 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
                                                              // and were 0-3 % slower for K = 3, 5, 7
     WR nx[2 * DP];
 #pragma unroll
-    for (int s = 0; s < 2 * DP; ++s) load_win<C, R>(nx[s], row(2 * (NP - 1) + s), b0);
+    for (int s = 0; s < 2 * DP; ++s) load_win<C, R>(nx[s], row(2 * (NP - 1) + s), b0, g.L);
     for (int j0 = 0; 2 * j0 < nrows; j0 += NP) {
 #pragma unroll
         for (int s = 0; s < NP; ++s) {
+            fix_edges<C, R>(nx[2 * (s % DP)], first, last);
+            fix_edges<C, R>(nx[2 * (s % DP) + 1], first, last);
             make_pair<C, K>(pl[(s + NP - 1) % NP], ph[(s + NP - 1) % NP], nx[2 * (s % DP)], nx[2 * (s % DP) + 1], t);
             const int tn = 2 * (j0 + s + NP - 1 + DP);        // refill the two slots just consumed
-            load_win<C, R>(nx[2 * (s % DP)], row(tn), b0);
-            load_win<C, R>(nx[2 * (s % DP) + 1], row(tn + 1), b0);
+            load_win<C, R>(nx[2 * (s % DP)], row(tn), b0, g.L);
+            load_win<C, R>(nx[2 * (s % DP) + 1], row(tn + 1), b0, g.L);
             const int y = 2 * (j0 + s);
 #pragma unroll
             for (int odd = 0; odd < 2; ++odd) {
@@ -442,15 +483,15 @@ __global__ __launch_bounds__(256) void sep_cols_kernel(const uint16_t* __restric
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
-// Tuning knobs exist in development builds only (make EXTRA=-DIPX_DEV) and are read once per process.
+// Tuning knobs exist in development builds only (make dev -> lib_dev/libipx.so, -DIPX_DEV); the shipped library reads none.
 #ifdef IPX_DEV
 int env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
 }
-int dev_seg_rows() { static const int v = env_int("IPX_SEG_ROWS", 0); return v; }
-int dev_wpb() { static const int v = env_int("IPX_WPB", 0); return v; }
+int dev_seg_rows() { return env_int("IPX_SEG_ROWS", 0); }   // (development build: re-read on every call, for sweeps)
+int dev_wpb() { return env_int("IPX_WPB", 0); }
 #else
 constexpr int dev_seg_rows() { return 0; }
 constexpr int dev_wpb() { return 0; }
@@ -471,13 +512,13 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
     g.trace = nullptr;
 #endif
     const int hd4 = 4 * ((r * c + 3) / 4);
-    // main-region lane i covers bytes [16 + 16 i, 32 + 16 i) and reads hd4 bytes on either side of them
-    g.nlanes = g.L >= 32 + hd4 ? (g.L - 32 - hd4) / 16 + 1 : 0;
+    // lane i covers bytes [16 i, 16 i + 16) and reads hd4 bytes on either side of them; the last two lanes are shifted
+    // left to end inside the row (lane_b0), which needs rows of at least 32 + hd4 bytes
+    g.nlanes = g.L >= 32 + hd4 ? (g.L + 15) / 16 : 0;
     // Strips are 64 lanes = 1 KiB of the row starting at byte 0, so that every wave's loads and stores cover whole
-    // 128-byte lines (measured: strips shifted by 16 bytes stream 10 % slower, scripts/dev/walkbench2.hip); lane 0 of
-    // strip 0 (border bytes) idles.
+    // 128-byte lines (measured: strips shifted by 16 bytes stream 10 % slower, scripts/dev/walkbench2.hip).
     g.lanes_per_strip = 64;
-    g.nstrips = g.nlanes ? (g.nlanes + 1 + 63) / 64 : 0;
+    g.nstrips = (g.nlanes + 63) / 64;
     // rows per segment: short enough for >= ~4 waves of work per wave slot, long enough to amortise the
     // 2r halo rows every segment re-reads
     int seg = dev_seg_rows();
@@ -508,7 +549,7 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
     g.blocks_per_seg = g.nstrips ? (g.nstrips + want - 1) / want : 1;
     g.wpb = g.nstrips ? (g.nstrips + g.blocks_per_seg - 1) / g.blocks_per_seg : 1;
     const uint64_t blocks = (uint64_t)n * g.nsegs * (g.nstrips ? g.blocks_per_seg : 0);
-    g.nb = g.nlanes > 0 ? 16 + (g.L - 16 - 16 * g.nlanes) : g.L;
+    g.nb = g.nlanes > 0 ? 0 : g.L;
     const uint64_t btotal = (uint64_t)n * h * g.nb;
     if (blocks > 0x3fffffffull || btotal > 0xffffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many work items", fn);
     g.main_blocks = (unsigned)blocks;
@@ -524,7 +565,7 @@ int launch_conv3(const char* fn, void* stream, const uint8_t* src, uint8_t* dst,
                  int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* top, const uint8_t* bot)
 {
     ConvGeom g;
-    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, 1, kMaxWavesPerBlock, 4, s_row, s_img, d_row, d_img, top, bot)) return rc;
+    if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, 1, kMaxWavesPerBlock, kConv3U, s_row, s_img, d_row, d_img, top, bot)) return rc;
     const dim3 grid(conv_grid(g)), block(conv_block(g));
     hipStream_t st = (hipStream_t)stream;
     switch (c) {

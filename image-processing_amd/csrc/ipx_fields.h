@@ -26,8 +26,14 @@ struct Win {                            // bytes [b0 - 4*HD, b0 + 16 + 4*HD) of 
     uint32_t w[ND];
 };
 
+// b0 = first of the lane's 16 row bytes, L = row bytes.  The two lanes at the ends of a row have no neighbours to take
+// halo bytes from: their halo loads are redirected to bytes inside the row (never before the row's first or behind its
+// last byte: the row may be the buffer's first or last) and fix_edges() then builds the halo by REFLECT_101.
+// (Tried and dropped, round 2: halo dwords from the neighbouring lanes' registers by DPP wave shifts, with memory
+// loads only for the lanes at a wave's ends: 2 % faster for 3 and 5 taps on BGR, 30 % slower for 7 taps -- the loads
+// inside divergent branches cost the compiler its exact vmcnt bookkeeping; and nt main loads: 8 % slower per step.)
 template <int C, int R>
-__device__ __forceinline__ void load_win(Win<C, R>& W, const uint8_t* rp, int b0)
+__device__ __forceinline__ void load_win(Win<C, R>& W, const uint8_t* rp, int b0, int L)
 {
     constexpr int HD = Win<C, R>::HD;
 #if IPX_CONV_NT_LOADS
@@ -40,9 +46,54 @@ __device__ __forceinline__ void load_win(Win<C, R>& W, const uint8_t* rp, int b0
 #pragma unroll
     for (int i = 0; i < HD; ++i) { W.w[i] = W.w[HD + i]; W.w[HD + 4 + i] = W.w[HD + 3 - i]; }
 #else
-    __builtin_memcpy(&W.w[0], rp + b0 - 4 * HD, 4 * HD);
-    __builtin_memcpy(&W.w[HD + 4], rp + b0 + 16, 4 * HD);
+    const int lo = b0 >= 4 * HD ? b0 - 4 * HD : b0;
+    const int hi = b0 + 16 + 4 * HD <= L ? b0 + 16 : b0 + 16 - 4 * HD;
+    __builtin_memcpy(&W.w[0], rp + lo, 4 * HD);
+    __builtin_memcpy(&W.w[HD + 4], rp + hi, 4 * HD);
 #endif
+}
+
+// Halo bytes of the lane that starts a row (b0 == 0) / ends it (b0 + 16 == L), mirrored about the first / last PIXEL
+// (cv::BORDER_REFLECT_101, channels interleaved): position -m is pixel -ceil(m / C) -> pixel +ceil(m / C), all of which
+// lie inside the lane's own 16 bytes because (R + 1) * C <= 16.  Only the R * C bytes the taps reach are produced.
+// Divergent, but only in the two waves of a row that hold these lanes.
+template <int C, int R>
+__device__ __forceinline__ void fix_edges(Win<C, R>& W, bool first, bool last)
+{
+    constexpr int HD = Win<C, R>::HD;
+    static_assert((R + 1) * C <= 16, "mirrored pixels must lie inside the lane's own 16 bytes");
+    if (first) {
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = 4 * (HD - d) - k;                    // this byte is row position -m
+                const int px = (m + C - 1) / C, ch = px * C - m;   // pixel -px, channel ch
+                if (px <= R) {
+                    const int sb = px * C + ch;                    // its mirror image: pixel +px
+                    out |= ((W.w[HD + (sb >> 2)] >> (8 * (sb & 3))) & 255u) << (8 * k);
+                }
+            }
+            W.w[d] = out;
+        }
+    }
+    if (last) {
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = 4 * d + k;                           // this byte is row position L + t: pixel w + t / C
+                const int j = t / C, ch = t - j * C;
+                if (j < R) {
+                    const int sb = 16 - (2 + j) * C + ch;          // pixel w - 2 - j, relative to b0 = L - 16
+                    out |= ((W.w[HD + (sb >> 2)] >> (8 * (sb & 3))) & 255u) << (8 * k);
+                }
+            }
+            W.w[HD + 4 + d] = out;
+        }
+    }
 }
 
 // Field pair (byte p, byte p+2) of the window, zero-extended to 2 x u16; p is relative to b0 and static.

@@ -12,8 +12,8 @@
 #include <stdlib.h>
 #include <atomic>
 
-extern "C" int ipx_lut_dev_u8(void*, const uint8_t*, uint8_t*, int, int, int, int, int64_t, int64_t, int64_t, int64_t,
-                              const uint8_t*, int64_t);
+int ipx_lut_dev_reversed(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                         int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* lut_dev, int64_t lut_stride);
 
 namespace {
 
@@ -316,7 +316,8 @@ int equalize_with_workspace(hipStream_t st, const uint8_t* src, uint8_t* dst, in
     hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, st, ws.partial, nparts,
                        (const uint32_t*)nullptr, hist_out_dev, lut);
     IPX_LAUNCH_CHECK("hist_finish_kernel");
-    return ipx_lut_dev_u8((void*)st, src, dst, n, h, w, 1, s_row, s_img, d_row, d_img, lut, 256);
+    // the table pass walks the batch back to front: what the histogram pass read last is still in the Infinity Cache
+    return ipx_lut_dev_reversed((void*)st, src, dst, n, h, w, s_row, s_img, d_row, d_img, lut, 256);
 }
 
 // ---- scratch of the no-allocation entry point ---------------------------------------------------------------------
@@ -490,7 +491,7 @@ int ipx_bgr2gray_equalize_u8(void* stream, const uint8_t* src, uint8_t* gray, ui
         if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "%s: launch of hist_finish_kernel failed", fn);
     }
     if (rc == IPX_OK)
-        rc = ipx_lut_dev_u8(stream, gray, dst, n, h, w, 1, gray_row_stride, gray_img_stride, dst_row_stride, dst_img_stride, lut, 256);
+        rc = ipx_lut_dev_reversed(stream, gray, dst, n, h, w, gray_row_stride, gray_img_stride, dst_row_stride, dst_img_stride, lut, 256);
     if (own) {
         hipError_t e = hipFreeAsync(own, st);
         if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));

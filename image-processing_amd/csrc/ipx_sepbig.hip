@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kThreads) void sep_h_kernel(const uint8_t* __restri
     const unsigned img = rest / (unsigned)g.rows_tmp;
     const int b0 = g.off + 16 * (int)lane;
     Win<C, RMAX> W;
-    load_win<C, RMAX>(W, src_row(g, src + (int64_t)img * g.s_img, trow - g.r), b0);
+    load_win<C, RMAX>(W, src_row(g, src + (int64_t)img * g.s_img, trow - g.r), b0, g.L);
     us2 h[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
