@@ -440,6 +440,119 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
 #endif
 }
 
+// ---- erode / dilate with a small structuring element (cv2.erode / cv2.dilate, server.py:433-434) -------------------
+// Same strip walker, gray images.  A structuring element of K x K (K = 3 or 5) whose non-empty rows use at most two
+// distinct column masks (every rectangle, cross and OpenCV ellipse of that size does): per source row each lane forms,
+// for its 8 field pairs, the horizontal min / max over mask A and over mask B (v_pk_min_u16 / v_pk_max_u16 on fields);
+// the vertical combine picks A or B per structuring-element row from a register ring of the last K rows.  Pixels
+// outside the image do not take part (OpenCV's default morphology border): their bytes and rows are the neutral value.
+struct MorphSE { uint32_t mask[2]; int sel[5]; };            // sel[i]: 0 = row i of the element is empty, 1 = mask A, 2 = mask B
+
+template <bool DILATE> __device__ __forceinline__ us2 mm(us2 a, us2 b)
+{
+    return DILATE ? __builtin_elementwise_max(a, b) : __builtin_elementwise_min(a, b);
+}
+
+template <bool DILATE, int R>
+__global__ __launch_bounds__(256) void morph_small_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                          ConvGeom g, MorphSE se)
+{
+    constexpr int K = 2 * R + 1;
+    typedef Win<1, R> WR;
+    constexpr int HD = WR::HD;
+    constexpr uint32_t NEU = DILATE ? 0u : 0xffffffffu;          // neutral bytes
+    const us2 neu = __builtin_bit_cast(us2, DILATE ? 0u : 0x00ff00ffu);
+    unsigned img; int y0, y1, lane0;
+    if (!wave_item(g, img, y0, y1, lane0)) return;
+    const int gl = lane0 + (int)(threadIdx.x & 63u);
+    if (gl >= g.nlanes) return;
+    const int b0 = lane_b0(g, gl);
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    const int nrows = y1 - y0;
+    const bool useB = se.mask[1] != 0;                           // wave-uniform
+
+    auto row_y = [&](int t) { return y0 - R + t; };              // source row of walk step t
+    auto row_ptr_cl = [&](int t) {
+        int yy = row_y(t);
+        yy = yy < 0 ? 0 : yy > g.h - 1 ? g.h - 1 : yy;           // rows outside the image are loaded clamped and then ignored
+        return simg + (int64_t)yy * g.s_row;
+    };
+    us2 ha[K][8], hb[K][8];                                      // ring: horizontal results of the last K source rows
+    auto feat = [&](us2 (&fa)[8], us2 (&fb)[8], WR& W, int t) {
+        const int yy = row_y(t);
+        if (yy < 0 || yy >= g.h) {                               // wave-uniform
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { fa[s] = neu; fb[s] = neu; }
+            return;
+        }
+        if (first) {
+#pragma unroll
+            for (int i = 0; i < HD; ++i) W.w[i] = NEU;
+        }
+        if (last) {
+#pragma unroll
+            for (int i = 0; i < HD; ++i) W.w[HD + 4 + i] = NEU;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int p = slot_p(s);
+            us2 a = neu, b = neu;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const us2 f = fld<1, R>(W, p + j - R);
+                if (se.mask[0] >> j & 1u) a = mm<DILATE>(a, f);      // wave-uniform
+                if (useB && (se.mask[1] >> j & 1u)) b = mm<DILATE>(b, f);
+            }
+            fa[s] = a;
+            fb[s] = b;
+        }
+    };
+    WR nx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) load_win<1, R>(nx[j], row_ptr_cl(j), b0, g.L);
+    // prologue: the first K - 1 source rows fill ring slots 0 .. K - 2 (and their windows are refilled)
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+        feat(ha[j], hb[j], nx[j], j);
+        load_win<1, R>(nx[j], row_ptr_cl(K + j), b0, g.L);
+    }
+    // step t (source row t, t >= K - 1) completes output row t - (K - 1); the loop is unrolled by K so that ring and window
+    // slots are static: step t uses slot t % K
+    for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += K) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const int t = t0 + q;
+            constexpr int dummy = 0; (void)dummy;
+            const int slot = (K - 1 + q) % K;                    // = t % K because t0 = K - 1 (mod K)
+            feat(ha[slot], hb[slot], nx[slot], t);
+            load_win<1, R>(nx[slot], row_ptr_cl(t + K), b0, g.L);
+            const int yo = t - (K - 1);
+            if (yo < nrows) {
+                us2 o[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) o[s] = neu;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {                    // element row i meets source row yo + i = ring slot (slot + 1 + i) % K
+                    const int rs = (slot + 1 + i) % K;
+                    if (se.sel[i] == 1) {
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) o[s] = mm<DILATE>(o[s], ha[rs][s]);
+                    } else if (se.sel[i] == 2) {
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) o[s] = mm<DILATE>(o[s], hb[rs][s]);
+                    }
+                }
+                u32x4 ov;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ov[k] = pack_fields(o[2 * k], o[2 * k + 1]);
+                st16_nt(dimg + (int64_t)(y0 + yo) * g.d_row + b0, ov);
+            }
+        }
+    }
+}
+
 // ---- generic two-pass path (any odd K <= IPX_MAX_GAUSS_K) -----------------------------------------------
 struct TapsBig { uint16_t k[IPX_MAX_GAUSS_K + 1]; };
 
@@ -605,6 +718,42 @@ void launch_sep_small_c(hipStream_t st, const uint8_t* src, uint8_t* dst, const 
 }
 
 }  // namespace
+
+// Called by ipx_morph_u8 (ipx_rank.hip) for structuring elements the strip walker handles: returns 1 if it launched,
+// 0 if the element does not qualify (larger than 5 x 5, more than two distinct row masks, rows too short), < 0 on error.
+int ipx_morph_small(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                    int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, int dilate,
+                    const uint32_t* row_bits, int se_rows, int se_cols)
+{
+    if (se_rows != se_cols || (se_rows != 3 && se_rows != 5)) return 0;
+    MorphSE se{};
+    int nm = 0;
+    for (int i = 0; i < se_rows; ++i) {
+        if (!row_bits[i]) { se.sel[i] = 0; continue; }
+        int m = -1;
+        for (int q = 0; q < nm; ++q) if (se.mask[q] == row_bits[i]) m = q;
+        if (m < 0) {
+            if (nm == 2) return 0;
+            se.mask[nm] = row_bits[i];
+            m = nm++;
+        }
+        se.sel[i] = m + 1;
+    }
+    const int r = se_rows / 2;
+    ConvGeom g;
+    if (int rc = make_conv_geom("ipx_morph_u8", g, src, dst, n, h, w, 1, r, 4, 2 * r + 1, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
+    if (g.nlanes == 0) return 0;                                 // rows too short for the vector lanes: the tile kernel
+    const dim3 grid(conv_grid(g)), block(conv_block(g));
+    if (r == 1) {
+        if (dilate) hipLaunchKernelGGL((morph_small_kernel<true, 1>), grid, block, 0, st, src, dst, g, se);
+        else hipLaunchKernelGGL((morph_small_kernel<false, 1>), grid, block, 0, st, src, dst, g, se);
+    } else {
+        if (dilate) hipLaunchKernelGGL((morph_small_kernel<true, 2>), grid, block, 0, st, src, dst, g, se);
+        else hipLaunchKernelGGL((morph_small_kernel<false, 2>), grid, block, 0, st, src, dst, g, se);
+    }
+    if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of morph_small_kernel failed");
+    return 1;
+}
 
 extern "C" {
 

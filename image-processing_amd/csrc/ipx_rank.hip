@@ -2,15 +2,19 @@
 // mode=denoise_manual with method=median (server.py:214-216).  SURVEY.md section 8(f) row 4.  Gray images.
 //
 //   cv2.medianBlur(img, k)        uint8, odd k (3..31 here), BORDER_REPLICATE: the (k*k-1)/2-th smallest of the k x k
-//                                 window.  Exact integer result, so any algorithm agrees: k = 3, 5, 7 run a selection
-//                                 network in registers (two pixels per thread, packed 16-bit min/max); larger k an 8-step
-//                                 binary search on the value, counting window pixels <= mid from an LDS tile.
+//                                 window.  Exact integer result, so any algorithm agrees: k <= 9 run a forgetful
+//                                 selection in registers (two pixels per thread, packed 16-bit min/max); larger k
+//                                 sliding per-column histograms in LDS (constant work per pixel).
 //   cv2.erode / cv2.dilate        min / max over the structuring element's non-zero positions (anchor = centre); pixels
 //                                 outside the image are ignored (OpenCV's default border value: +inf for erode, -inf for
 //                                 dilate).  cv2.morphologyEx OPEN = dilate(erode), CLOSE = erode(dilate): composed by the
 //                                 host from these two.
 // OpenCV is absent from this image: these restate its published definitions (parity unpinned).
 #include "ipx_common.h"
+
+int ipx_morph_small(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                    int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, int dilate,
+                    const uint32_t* row_bits, int se_rows, int se_cols);
 
 namespace {
 
@@ -361,6 +365,10 @@ int ipx_morph_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, i
     RankGeom g;
     unsigned blocks = 0;
     if (int rc = make_geom(fn, g, src, dst, n, h, w, se_cols / 2, se_rows / 2, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride, &blocks)) return rc;
+    // 3 x 3 and 5 x 5 elements with at most two distinct row masks (every rectangle, cross and ellipse): strip walker
+    if (int rc = ipx_morph_small((hipStream_t)stream, src, dst, n, h, w, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride,
+                                 op, se.bits, se_rows, se_cols))
+        return rc < 0 ? rc : IPX_OK;
     if (op) hipLaunchKernelGGL(morph_kernel<true>, dim3(blocks), dim3(kTileW * kTileH), 0, (hipStream_t)stream, src, dst, g, se);
     else hipLaunchKernelGGL(morph_kernel<false>, dim3(blocks), dim3(kTileW * kTileH), 0, (hipStream_t)stream, src, dst, g, se);
     IPX_LAUNCH_CHECK("morph_kernel");

@@ -512,3 +512,24 @@ print("ok")
     env = dict(os.environ, IPX_NT_BYTES="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 17), (5, 44), (9, 45), (33, 70), (40, 342), (21, 1030), (18, 2051), (130, 96)])
+def test_morphology_small_elements_strip_walker(dev, shape):
+    """3 x 3 / 5 x 5 elements with at most two distinct row masks run on the strip walker (ipx_conv.hip): asymmetric
+    elements (orientation), empty rows, rectangles, crosses, ellipses, and an element with three masks (tile kernel);
+    widths around the 44-byte vector threshold and ragged 16-byte tails; erode <= src <= dilate where the centre is set."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    t = dev_t(img, dev)
+    ses = [np.ones((3, 3), np.uint8), np.ones((5, 5), np.uint8), ops.ellipse_se(3), ops.ellipse_se(5),
+           np.array([[1, 0, 0], [1, 1, 0], [1, 0, 0]], np.uint8), np.array([[0, 0, 0], [0, 1, 1], [0, 0, 0]], np.uint8),
+           np.array([[0, 0, 1, 1, 0], [1, 0, 0, 0, 1], [0, 0, 0, 0, 0], [1, 0, 0, 0, 1], [0, 0, 1, 1, 0]], np.uint8),
+           np.array([[1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 1, 0, 0], [0, 1, 0, 0, 0], [1, 0, 0, 0, 0]], np.uint8)]
+    for se in ses:
+        np.testing.assert_array_equal(host(ops.erode(t, se)), O.erode_u8(img, se), err_msg=f"erode {se.tolist()}")
+        np.testing.assert_array_equal(host(ops.dilate(t, se)), O.dilate_u8(img, se), err_msg=f"dilate {se.tolist()}")
+    batch = rng.integers(0, 256, (3,) + shape + (1,), dtype=np.uint8)
+    got = host(ops.dilate(dev_t(batch, dev), ops.ellipse_se(5)))
+    for i in range(3):
+        np.testing.assert_array_equal(got[i, :, :, 0], O.dilate_u8(batch[i, :, :, 0], ops.ellipse_se(5)))
