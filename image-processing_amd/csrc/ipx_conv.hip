@@ -440,6 +440,94 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
 #endif
 }
 
+// ---- 3- and 5-tap filters whose taps are a power of two times small SYMMETRIC integers -----------------------------
+// cv2.GaussianBlur's own 3 x 3 and 5 x 5 kernels are 64 * [1 2 1] and 16 * [1 4 6 4 1] in Q0.8.  With kx = gx * kx',
+// ky = gy * ky', gx * gy = 2^m and 255 * sum(kx') * sum(ky') + rounding < 2^16, the whole filter is exact in PACKED
+// 16-bit arithmetic: row pass B = sum kx'[j] s[x + j] and column pass S = sum ky'[i] B[y + i] both fit 16 bits, and
+// (256-scaled sum + 2^15) >> 16 == (S + 2^(15 - m)) >> (16 - m).  Symmetry (outer tap 1) halves the multiplies:
+// (a + e) + k1 (b + d) + k2 c is two packed adds and two packed multiply-adds for two pixels, in both passes -- about
+// 100 vector instructions per 16 bytes and row against 150 for the general kernel (v_pk_mad_u16 row pass, v_dot2 column
+// pass on row pairs), which is bound by vector issue, not by memory (SQ_WAIT_INST_ANY 59 %, profiles/r02_notes.md).
+struct Pow2Taps { uint32_t kx1, kx2, ky1, ky2, rnd, sh; };       // inner taps (K = 3: k1 = centre, k2 unused), rounding, shift
+
+template <int C, int K>
+__global__ __launch_bounds__(64 * kMaxWavesPerBlock) void sep_pow2_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                       ConvGeom g, Pow2Taps t)
+{
+    constexpr int R = K / 2;
+    typedef Win<C, R> WR;
+    unsigned img; int y0, y1, lane0;
+    if (!wave_item(g, img, y0, y1, lane0)) return;
+    const int gl = lane0 + (int)(threadIdx.x & 63u);
+    if (gl >= g.nlanes) return;
+    const int b0 = lane_b0(g, gl);
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    const int nrows = y1 - y0;
+    const int tlast = nrows - 1 + 2 * R;                         // last source row of the walk anybody needs
+    auto row = [&](int tt) { return row_ptr(g, simg, y0 + ((tt <= tlast ? tt : tlast) - R), R); };   // walk row tt
+    const unsigned short kx1 = (unsigned short)t.kx1, kx2 = (unsigned short)t.kx2;
+    const unsigned short ky1 = (unsigned short)t.ky1, ky2 = (unsigned short)t.ky2;
+    const us2 rnd = {(unsigned short)t.rnd, (unsigned short)t.rnd};
+    const us2 sh = {(unsigned short)t.sh, (unsigned short)t.sh};
+
+    us2 hb[K][8];                                                // ring: row-pass results of the last K source rows
+    auto hpass = [&](us2 (&h)[8], WR& W) {
+        fix_edges<C, R>(W, first, last);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int p = slot_p(s);
+            if (K == 3) {
+                h[s] = (fld<C, R>(W, p - C) + fld<C, R>(W, p + C)) + fld<C, R>(W, p) * kx1;
+            } else {
+                const us2 o = fld<C, R>(W, p - 2 * C) + fld<C, R>(W, p + 2 * C);
+                const us2 i = fld<C, R>(W, p - C) + fld<C, R>(W, p + C);
+                h[s] = (o + i * kx1) + fld<C, R>(W, p) * kx2;
+            }
+        }
+    };
+    WR nx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) load_win<C, R>(nx[j], row(j), b0, g.L);
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {                            // prologue: source rows 0 .. K - 2 -> ring slots 0 .. K - 2
+        hpass(hb[j], nx[j]);
+        load_win<C, R>(nx[j], row(K + j), b0, g.L);
+    }
+    // walk step tt (source row tt, tt >= K - 1) completes output row tt - (K - 1); unrolled by K: ring and window slot
+    // tt % K are static
+    for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += K) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const int tt = t0 + q;
+            const int slot = (K - 1 + q) % K;                    // = tt % K
+            hpass(hb[slot], nx[slot]);
+            load_win<C, R>(nx[slot], row(tt + K), b0, g.L);
+            const int yo = tt - (K - 1);
+            if (yo < nrows) {
+                us2 o[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {                    // source rows yo .. yo + K - 1 = ring slots (slot + 1 + i) % K
+                    us2 v;
+                    if (K == 3) {
+                        v = (hb[(slot + 1) % K][s] + hb[slot][s]) + (hb[(slot + 2) % K][s] * ky1 + rnd);
+                    } else {
+                        const us2 oo = hb[(slot + 1) % K][s] + hb[slot][s];
+                        const us2 ii = hb[(slot + 2) % K][s] + hb[(slot + 4) % K][s];
+                        v = (oo + ii * ky1) + (hb[(slot + 3) % K][s] * ky2 + rnd);
+                    }
+                    o[s] = v >> sh;
+                }
+                u32x4 ov;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ov[k] = pack_fields(o[2 * k], o[2 * k + 1]);
+                st16_nt(dimg + (int64_t)(y0 + yo) * g.d_row + b0, ov);
+            }
+        }
+    }
+}
+
 // ---- erode / dilate with a small structuring element (cv2.erode / cv2.dilate, server.py:433-434) -------------------
 // Same strip walker, gray images.  A structuring element of K x K (K = 3 or 5) whose non-empty rows use at most two
 // distinct column masks (every rectangle, cross and OpenCV ellipse of that size does): per source row each lane forms,
@@ -542,6 +630,88 @@ __global__ __launch_bounds__(256) void morph_small_kernel(const uint8_t* __restr
                     } else if (se.sel[i] == 2) {
 #pragma unroll
                         for (int s = 0; s < 8; ++s) o[s] = mm<DILATE>(o[s], hb[rs][s]);
+                    }
+                }
+                u32x4 ov;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ov[k] = pack_fields(o[2 * k], o[2 * k + 1]);
+                st16_nt(dimg + (int64_t)(y0 + yo) * g.d_row + b0, ov);
+            }
+        }
+    }
+}
+
+// ---- 3 x 3 median (cv2.medianBlur(gray, 3), server.py:436) on the strip walker --------------------------------------
+// Gray images, BORDER_REPLICATE.  Per output row a lane sorts the 3 vertical values of each of its 16 columns' field pairs
+// (lo, mid, hi: 6 packed min / max) and takes, per pixel, med3(max of the three neighbouring lo, med3 of the mid, min of
+// the hi) -- the classic exact 3 x 3 median from sorted columns; neighbouring pixels share the pair min / max.  About 200
+// vector instructions per 16 pixels (the tile kernel in ipx_rank.hip sorts 9 values per pixel from scratch).
+__device__ __forceinline__ us2 umin2(us2 a, us2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ us2 umax2(us2 a, us2 b) { return __builtin_elementwise_max(a, b); }
+
+__global__ __launch_bounds__(64 * kMaxWavesPerBlock) void median3_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, ConvGeom g)
+{
+    constexpr int K = 3, NQ = 16;                                // fields q = -1 .. 14
+    typedef Win<1, 1> WR;
+    unsigned img; int y0, y1, lane0;
+    if (!wave_item(g, img, y0, y1, lane0)) return;
+    const int gl = lane0 + (int)(threadIdx.x & 63u);
+    if (gl >= g.nlanes) return;
+    const int b0 = lane_b0(g, gl);
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    const int nrows = y1 - y0;
+    auto row = [&](int t) {                                      // walk step t = source row y0 - 1 + t, replicated at the ends
+        int yy = y0 - 1 + t;
+        yy = yy < 0 ? 0 : yy > g.h - 1 ? g.h - 1 : yy;
+        return simg + (int64_t)yy * g.s_row;
+    };
+    us2 f[K][NQ];                                                // ring: the field pairs of the last 3 source rows
+    auto fields = [&](us2 (&o)[NQ], WR& W) {
+        if (first) W.w[0] = W.w[1] << 24;                        // byte -1 = byte 0
+        if (last) W.w[5] = W.w[4] >> 24;                         // byte 16 = byte 15
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) o[q] = fld<1, 1>(W, q - 1);
+    };
+    WR nx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) load_win<1, 1>(nx[j], row(j), b0, g.L);
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+        fields(f[j], nx[j]);
+        load_win<1, 1>(nx[j], row(K + j), b0, g.L);
+    }
+    for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += K) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int t = t0 + u;
+            const int slot = (K - 1 + u) % K;                    // = t % K
+            fields(f[slot], nx[slot]);
+            load_win<1, 1>(nx[slot], row(t + K), b0, g.L);
+            const int yo = t - (K - 1);
+            if (yo < nrows) {
+                us2 lo[NQ], mid[NQ], hi[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {                   // sort the column (the order of the three rows does not matter)
+                    const us2 a = f[0][q], b = f[1][q], c = f[2][q];
+                    const us2 mn = umin2(a, b), mx = umax2(a, b);
+                    lo[q] = umin2(mn, c);
+                    hi[q] = umax2(mx, c);
+                    mid[q] = umax2(mn, umin2(mx, c));
+                }
+                us2 o[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {                    // slots 2k, 2k + 1 = fields p, p + 1 with p = 4k; array index = q + 1
+                    const int i = 4 * k + 1;
+                    const us2 ml = umax2(lo[i], lo[i + 1]), mh = umin2(hi[i], hi[i + 1]);
+                    const us2 mn = umin2(mid[i], mid[i + 1]), mx = umax2(mid[i], mid[i + 1]);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = e ? i + 2 : i - 1;         // the third column: p - 1 for slot p, p + 2 for slot p + 1
+                        const us2 A = umax2(ml, lo[j]), C = umin2(mh, hi[j]);
+                        const us2 B = umax2(mn, umin2(mx, mid[j]));
+                        o[2 * k + e] = umax2(umin2(A, B), umin2(umax2(A, B), C));
                     }
                 }
                 u32x4 ov;
@@ -717,6 +887,42 @@ void launch_sep_small_c(hipStream_t st, const uint8_t* src, uint8_t* dst, const 
     }
 }
 
+
+// Taps of the form g * [1 k1 (k2 k1) 1] with g a power of two (see sep_pow2_kernel): fills `out`, returns false otherwise.
+bool pow2_symmetric_taps(const uint16_t* kx, const uint16_t* ky, int k, Pow2Taps* out)
+{
+    if (k != 3 && k != 5) return false;
+    auto split = [&](const uint16_t* t, unsigned* g, unsigned* k1, unsigned* k2) {
+        const unsigned g0 = t[0];
+        if (g0 == 0 || (g0 & (g0 - 1)) != 0) return false;       // outer tap: a power of two, and every tap a multiple of it
+        for (int i = 0; i < k; ++i) if (t[i] != t[k - 1 - i] || t[i] % g0) return false;
+        *g = g0; *k1 = t[1] / g0; *k2 = k == 5 ? t[2] / g0 : 0;
+        return true;
+    };
+    unsigned gx, gy, kx1, kx2, ky1, ky2;
+    if (!split(kx, &gx, &kx1, &kx2) || !split(ky, &gy, &ky1, &ky2)) return false;
+    unsigned m = 0;
+    while ((1u << m) < gx * gy) ++m;                             // gx * gy = 2^m (both powers of two)
+    if (m > 15) return false;
+    const unsigned sx = 256 / gx, sy = 256 / gy;                 // sums of the reduced taps (the taps sum to 256)
+    const unsigned rnd = 1u << (15 - m);
+    if (255u * sx * sy + rnd > 65535u) return false;
+    out->kx1 = kx1; out->kx2 = kx2; out->ky1 = ky1; out->ky2 = ky2; out->rnd = rnd; out->sh = 16 - m;
+    return true;
+}
+
+template <int K>
+void launch_sep_pow2(hipStream_t st, const uint8_t* src, uint8_t* dst, const ConvGeom& g, int c, const Pow2Taps& t)
+{
+    const dim3 grid(conv_grid(g)), block(conv_block(g));
+    switch (c) {
+        case 1: hipLaunchKernelGGL((sep_pow2_kernel<1, K>), grid, block, 0, st, src, dst, g, t); break;
+        case 2: hipLaunchKernelGGL((sep_pow2_kernel<2, K>), grid, block, 0, st, src, dst, g, t); break;
+        case 3: hipLaunchKernelGGL((sep_pow2_kernel<3, K>), grid, block, 0, st, src, dst, g, t); break;
+        default: hipLaunchKernelGGL((sep_pow2_kernel<4, K>), grid, block, 0, st, src, dst, g, t); break;
+    }
+}
+
 }  // namespace
 
 // Called by ipx_morph_u8 (ipx_rank.hip) for structuring elements the strip walker handles: returns 1 if it launched,
@@ -752,6 +958,19 @@ int ipx_morph_small(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int
         else hipLaunchKernelGGL((morph_small_kernel<false, 2>), grid, block, 0, st, src, dst, g, se);
     }
     if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of morph_small_kernel failed");
+    return 1;
+}
+
+// Called by ipx_median_blur_u8 (ipx_rank.hip) for k = 3: returns 1 if the strip walker launched, 0 if rows are too short
+// for its vector lanes (the tile kernel takes them), < 0 on error.
+int ipx_median3_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                       int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img)
+{
+    ConvGeom g;
+    if (int rc = make_conv_geom("ipx_median_blur_u8", g, src, dst, n, h, w, 1, 1, kMaxWavesPerBlock, 3, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
+    if (g.nlanes == 0) return 0;
+    hipLaunchKernelGGL(median3_kernel, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
+    if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median3_kernel failed");
     return 1;
 }
 
@@ -801,6 +1020,17 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
         uint8_t ident[256];
         for (int i = 0; i < 256; ++i) ident[i] = (uint8_t)i;
         return ipx_lut_u8(stream, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, ident);
+    }
+    Pow2Taps pt;
+    if (g.nlanes > 0 && pow2_symmetric_taps(kx_q8, ky_q8, k, &pt)
+#ifdef IPX_DEV
+        && !getenv("IPX_NO_POW2")                                     // A/B switch of development builds
+#endif
+    ) {                                                               // cv2.GaussianBlur's own 3- and 5-tap kernels
+        if (k == 3) launch_sep_pow2<3>(st, src, dst, g, c, pt);
+        else launch_sep_pow2<5>(st, src, dst, g, c, pt);
+        IPX_LAUNCH_CHECK("sep_pow2_kernel");
+        return IPX_OK;
     }
     if (k == 3) { launch_sep_small_c<3>(st, src, dst, g, c, kx_q8, ky_q8); IPX_LAUNCH_CHECK("sep_small_kernel<3>"); return IPX_OK; }
     if (k == 5) {

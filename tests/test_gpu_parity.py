@@ -201,6 +201,26 @@ def test_large_kernels_matrix_core_path(dev, cn):
         np.testing.assert_array_equal(got[i] if cn > 1 else got[i][:, :, 0], want)
 
 
+def test_gaussian_power_of_two_symmetric_taps(dev):
+    """taps g * [1 a (b a) 1] with g a power of two (cv2's own 3- and 5-tap Gaussians among them) run in packed 16-bit
+    arithmetic (sep_pow2_kernel); mixed scales per axis, the overflow boundary (which must fall back), 0/255 images."""
+    rng = np.random.default_rng(77)
+    cases = [([64, 128, 64], [64, 128, 64]), ([64, 128, 64], [32, 192, 32]), ([128, 0, 128], [64, 128, 64]),
+             ([16, 64, 96, 64, 16], [16, 64, 96, 64, 16]), ([16, 64, 96, 64, 16], [32, 32, 128, 32, 32]),
+             ([32, 64, 64, 64, 32], [64, 0, 128, 0, 64]),
+             ([16, 64, 96, 64, 16], [8, 24, 192, 24, 8]),            # 255 * 16 * 32 does not fit 16 bits: general kernel
+             ([1, 2, 250, 2, 1], [1, 2, 250, 2, 1])]
+    for cn in (1, 2, 3, 4):
+        for shape in ((40, 342), (9, 33), (130, 96), (3, 2051)):
+            full = shape + ((cn,) if cn > 1 else ())
+            imgs = [rng.integers(0, 256, full, dtype=np.uint8), np.where(rng.random(full) < 0.5, 0, 255).astype(np.uint8),
+                    np.full(full, 255, np.uint8)]
+            for kx, ky in cases:
+                for img in imgs:
+                    np.testing.assert_array_equal(host(ops.sep_filter_q8(dev_t(img, dev), kx, ky)),
+                                                  O.sep_filter_q8_u8(img, kx, ky), err_msg=f"{full} {kx} {ky}")
+
+
 def test_gaussian_max_values_do_not_overflow(dev):
     img = np.full((40, 1200, 3), 255, np.uint8)
     for k in (3, 5, 7, 15, 31):
@@ -347,6 +367,21 @@ def test_median_extremes_and_batch(dev):
     got = host(ops.median_blur(dev_t(batch, dev), 5))
     for i in range(3):
         np.testing.assert_array_equal(got[i, :, :, 0], O.median_blur_u8(batch[i, :, :, 0], 5))
+
+
+def test_median3_strip_walker(dev):
+    """k = 3 on rows long enough for the strip walker (sorted columns): widths around the 16-byte lane and 1 KiB strip
+    boundaries, heights around the row segments, few grey levels (many ties), a strided batch with an unaligned base."""
+    rng = np.random.default_rng(33)
+    for h, w in ((1, 36), (2, 47), (3, 48), (7, 49), (25, 64), (26, 1023), (50, 1024), (49, 1041), (130, 2051), (5, 4099)):
+        for levels in (256, 3):
+            img = (rng.integers(0, levels, (h, w)) * (255 // (levels - 1))).astype(np.uint8)
+            np.testing.assert_array_equal(host(ops.median_blur(dev_t(img, dev), 3)), O.median_blur_u8(img, 3), err_msg=f"{h}x{w}")
+    big = rng.integers(0, 256, (3, 60, 700), dtype=np.uint8)
+    view = dev_t(big, dev)[:, 5:55, 3:3 + 611].unsqueeze(-1)
+    got = host(ops.median_blur(view, 3))
+    for i in range(3):
+        np.testing.assert_array_equal(got[i, :, :, 0], O.median_blur_u8(np.ascontiguousarray(big[i, 5:55, 3:614]), 3))
 
 
 @pytest.mark.parametrize("k", [9, 11, 13, 21, 31])
