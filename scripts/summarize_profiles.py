@@ -18,6 +18,22 @@ def short(n):
 shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0], os.path.join(out, f"{name}_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(out, f"{name}_bench.json"))
 stats = {short(r["Name"]): r for r in csv.DictReader(open(os.path.join(out, f"{name}_kernel_stats.csv")))}
+# the stats CSV averages over EVERY launch, the one-image launches of bench.py's latency section included: the table
+# below uses the durations of the full-batch launches only (largest grid of each kernel), from the kernel trace
+full_us = {}
+tr = glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv"))
+if tr:
+    by = collections.defaultdict(list)
+    for r in csv.DictReader(open(tr[0])):
+        by[short(r["Kernel_Name"])].append((int(r["Grid_Size_X"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    for k, v in by.items():
+        gmax = max(g for g, _ in v)
+        d = sorted(t for g, t in v if g == gmax)
+        full_us[k] = (sum(d) / len(d), d[len(d) // 2], len(d))
+    with open(os.path.join(out, f"{name}_full_batch_launches.csv"), "w") as f:
+        f.write("kernel,launches,mean_us,median_us\n")
+        for k, (m, med, cnt) in sorted(full_us.items(), key=lambda kv: -kv[1][0] * kv[1][2]):
+            f.write(f"\"{k}\",{cnt},{m:.1f},{med:.1f}\n")
 pmc = collections.defaultdict(dict)
 for which, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     vals = collections.defaultdict(list)
@@ -29,8 +45,8 @@ for which, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 bench = json.load(open(os.path.join(src, "bench.json")))
 B = bench["config"]["batch_per_gpu"]
 px = B * 2160 * 3840
-alg_by_prefix = {"sep_pow2_kernel<3, 5>": 6, "sep_small_kernel<3, 5>": 6, "conv3_kernel<2, 1>": 2, "conv3_kernel<0, 3>": 6, "gray_hist_kernel<3": 4,
-                 "gray_kernel<3": 4, "lut_kernel<": 2, "hist_partial_kernel<": 1}   # the nt template variants share a row
+alg_by_prefix = {"sep_pow2_kernel<3, 5>": 6, "sep_small_kernel<3, 5>": 6, "conv3_kernel<2, 1>": 2, "conv3_kernel<0, 3>": 6, "gray_hist_kernel<3, true>": 4,
+                 "gray_kernel<3": 4, "lut_kernel<false, true>": 2, "lut_kernel<true, true>": 2, "hist_partial_kernel<": 1}   # the nt template variants share a row
 
 
 class _Alg:
@@ -46,13 +62,13 @@ lines = [f"# {name}: per-kernel duration and HBM-side traffic (batch {B} x 3840x
          "Source: `rocprofv3 --kernel-trace --stats` and two `--pmc` passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py`,",
          "collected by scripts/collect_profiles.sh.  Counters are KiB; FETCH_SIZE is doubled (gfx950 reports half the bytes of a",
          "wide coalesced stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE is taken as is.  `alg` = algorithmic bytes per launch.", "",
-         "| kernel | avg us | read MB (2 x FETCH_SIZE) | write MB | traffic MB | alg MB | traffic/alg | alg GB/s | frac of 8 TB/s |",
+         "| kernel | avg us (full-batch launches) | read MB (2 x FETCH_SIZE) | write MB | traffic MB | alg MB | traffic/alg | alg GB/s | frac of 8 TB/s |",
          "|---|---|---|---|---|---|---|---|---|"]
 traffic_json = {}
 for k, c in sorted(pmc.items()):
     if k not in stats or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         continue
-    us = float(stats[k]["AverageNs"]) / 1e3
+    us = full_us[k][0] if k in full_us else float(stats[k]["AverageNs"]) / 1e3
     rd, wr = 2 * c["FETCH_SIZE"] * 1024 / 1e6, c["WRITE_SIZE"] * 1024 / 1e6
     a = alg.get(k)
     amb = px * a / 1e6 if a else None
@@ -61,5 +77,5 @@ for k, c in sorted(pmc.items()):
     traffic_json[k] = int((rd + wr) * 1e6)
 open(os.path.join(out, f"{name}_pmc.md"), "w").write("\n".join(lines) + "\n")
 json.dump({"gaussian5_bgr": (traffic_json.get("sep_pow2_kernel<3, 5>") or traffic_json.get("sep_small_kernel<3, 5>")), "batch_per_gpu": B, "per_kernel_bytes": traffic_json,
-           "source": f"profiles/{name}_pmc.md"}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+           "source": f"profiles/{name}_pmc.md", "recorded_at": f"round {int(name[1:3])}" if name[1:3].isdigit() else name}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
