@@ -91,3 +91,38 @@ for nthreads in (1, 2, 4, 8, 16):
     dt = time.perf_counter() - t0
     rec = {"clients": nthreads, "requests_per_s": round(3 * nthreads / dt, 1), "MP_per_s": round(3 * nthreads * 8.2944 / dt, 1)}
     print("concurrent 4K gray gamma requests:", rec, flush=True)
+
+# ---- /api/process_batch: 8 files of 4K in ONE request; decode on the codec pool ahead of the per-GPU workers ----
+import contextlib
+
+
+class _NoAhead:                                            # the round-1 behaviour: every worker decodes its own file
+    def __init__(self, blobs): pass
+    def use(self, i): return contextlib.nullcontext()
+
+
+def batch_request(c, files, form):
+    t0 = time.perf_counter()
+    r = c.post("/api/process_batch", data={"file": [(io.BytesIO(b), f"{i}.png") for i, b in enumerate(files)], **form},
+               content_type="multipart/form-data")
+    assert r.status_code == 200 and all(x["status"] == 200 for x in r.get_json()["results"])
+    return time.perf_counter() - t0
+
+
+for label, c, form in (("gray gamma", 1, {"mode": "gamma", "gamma": "0.6"}), ("colour sharpening", 3, {"mode": "sharpening"})):
+    files = [png(smooth(2160, 3840, c)) for _ in range(8)]
+    cl = app.test_client()
+    rec = {}
+    real = codec.DecodeAhead
+    for name, cls in (("decode_ahead", real), ("decode_in_worker", _NoAhead)):
+        codec.DecodeAhead = cls
+        batch_request(cl, files, form)
+        rec[f"ms_{name}"] = round(1e3 * float(np.median([batch_request(cl, files, form) for _ in range(3)])), 1)
+    codec.DecodeAhead = real
+    t0 = time.perf_counter()
+    for b in files:
+        r = cl.post("/api/process", data={"file": (io.BytesIO(b), "x.png"), **form}, content_type="multipart/form-data")
+        assert r.status_code == 200
+    rec["ms_8_single_requests"] = round(1e3 * (time.perf_counter() - t0), 1)
+    rec["MP_per_s_decode_ahead"] = round(8 * 8.2944 / (rec["ms_decode_ahead"] * 1e-3), 1)
+    print(f"process_batch, 8 x 4K {label}:", rec, flush=True)
