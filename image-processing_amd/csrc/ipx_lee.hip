@@ -26,6 +26,33 @@ __device__ __forceinline__ float rn_add(float a, float b) { return a + b; }
 __device__ __forceinline__ float rn_sub(float a, float b) { return a - b; }
 __device__ __forceinline__ float rn_mul(float a, float b) { return a * b; }
 __device__ __forceinline__ float rn_div(float a, float b) { return a / b; }     // IEEE: HIP's default is the correctly rounded one
+
+typedef float f2 __attribute__((ext_vector_type(2)));                 // two pixels side by side: v_pk_*_f32
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// fl(a / n) for the constants n = 9, 25, 49 in three operations (Markstein's division by a constant: y = fl(a c) with
+// c = fl(1 / n), r = a - n y exactly (one FMA), q = fl(y + r c)).  Correctly rounded for EVERY float a whose quotient neither
+// overflows nor is subnormal -- checked exhaustively over all 2^23 significands by tests/test_oracle_golden.py
+// (test_markstein_division_by_window_size), and the three steps scale exactly with powers of two.
+__device__ __forceinline__ f2 div_by_const(f2 a, float n, float c)
+{
+    const f2 nn = f2{n, n}, cc = f2{c, c};
+    const f2 y = a * cc;
+    return fma2(fma2(-nn, y, a), cc, y);
+}
+
+// fl(a / b) for 2^-60 < a, 2^-8 < b < 2^20, a <= b (the Lee gain var / (var + q)): the operation sequence of the hardware's
+// own IEEE division (v_div_scale, v_rcp, 4 FMAs + 1 multiply for the refinement, v_div_fmas, v_div_fixup) with the parts
+// that only act on extreme exponents, zeros, infinities and NaNs left out: v_div_scale does not scale and v_div_fixup passes
+// the quotient through in this range, so the result is bit-identical to a / b (every Lee parity test goes through it).
+__device__ __forceinline__ f2 div_safe_range(f2 a, f2 b)
+{
+    f2 r = f2{__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+    r = fma2(fma2(-b, r, f2{1.0f, 1.0f}), r, r);
+    f2 q = a * r;
+    q = fma2(fma2(-b, q, a), r, q);
+    return fma2(fma2(-b, q, a), r, q);
+}
 }  // namespace
 
 namespace {
@@ -142,76 +169,103 @@ __global__ __launch_bounds__(kTileW * kTileH) void lee_kernel(const uint8_t* __r
 }
 
 
-// ---- windows of 3 x 3 and 5 x 5: a thread walks down one image column -------------------------------------------------
+// ---- windows of 3 x 3 and 5 x 5: a thread walks down two adjacent image columns ----------------------------------------
 // The general kernel above spends its time on LDS index tables and on four IEEE divisions per pixel.  For K = 3 and 5:
-//   * a lane owns column x and walks a segment of rows; per row ONE unaligned 4- or 8-byte load gives it bytes
-//     x-k .. x+k; the K x K window lives in registers as floats (ring of K rows, loop unrolled by K: static indices);
+//   * a lane owns columns x, x + 1 and walks a segment of rows; per row ONE unaligned 4- or 8-byte load gives it bytes
+//     x-k .. x+1+k; the two K x K windows live in registers as PAIRS of floats (window value i of the left and of the
+//     right pixel side by side), ring of K rows, loop unrolled by K: static indices.  All per-pixel arithmetic is then
+//     two-wide (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), every operation separately rounded as before;
 //   * the window sum S is an integer <= 255 n, so mean = fl(S / n) and q = fl(fl(mean^2) / fl(mean + 1e-12)) are
 //     functions of S alone: a (mean, q) table over all S is built per block in LDS with the very same operations
 //     (2 divisions per ENTRY instead of per pixel);
 //   * the squared deviations are summed in numpy's pairwise order for n < 128 (8 interleaved accumulators over
 //     floor(n / 8) rounds, a balanced tree, the remainder serially), all indices static;
-//   * two IEEE divisions per pixel remain (sum / n and var / (var + q)).
+//   * the two divisions per pixel that remain are sum / n (three operations, div_by_const) and var / (var + q) (the
+//     hardware division's own refinement steps without its range handling, div_safe_range).
 struct LeeSmallGeom {
     int h, w;
     int64_t s_row, s_img, d_row, d_img;
-    int seg_rows, nsegs, nstrips, blocks_per_seg;          // strip = 64 columns (one wave), block = 4 adjacent strips
+    int seg_rows, nsegs, nstrips, blocks_per_seg;          // strip = 128 columns (one wave), block = 4 adjacent strips
 };
 
 template <int K>
 __global__ __launch_bounds__(256) void lee_small_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, LeeSmallGeom g)
 {
-    constexpr int k = K / 2, n = K * K, NT = 255 * n + 1, LB = K <= 3 ? 4 : 8;   // LB: bytes per row load
-    extern __shared__ float2 s_tab[];                      // [S] = (mean, q)
-    const float fn = (float)n;
+    constexpr int k = K / 2, n = K * K, NT = 255 * n + 1, LB = K <= 3 ? 4 : 8;   // LB: bytes per row load (>= K + 1)
+    extern __shared__ float s_tab[];                       // mean[S] = s_tab[S], q[S] = s_tab[NT + S]
+    const float fn = (float)n, cn = rn_div(1.0f, fn);
     for (int i = (int)threadIdx.x; i < NT; i += 256) {
         const float m = rn_div((float)i, fn);
-        s_tab[i] = make_float2(m, rn_div(rn_mul(m, m), rn_add(m, 1e-12f)));
+        s_tab[i] = m;
+        // S = 0 (an all-zero window: var = 0, mean = 0) would give q = 0 and 0 / 0 below; any positive q there gives the
+        // reference's result (k_lee = 0, out = mean)
+        s_tab[NT + i] = i ? rn_div(rn_mul(m, m), rn_add(m, 1e-12f)) : 1.0f;
     }
     __syncthreads();
     const unsigned blk = blockIdx.x;
     const unsigned sub = blk % (unsigned)g.blocks_per_seg, rest = blk / (unsigned)g.blocks_per_seg;
     const unsigned seg = rest % (unsigned)g.nsegs, img = rest / (unsigned)g.nsegs;
-    const int x = (int)((sub * 4u + (threadIdx.x >> 6)) * 64u + (threadIdx.x & 63u));
+    const int x = 2 * (int)((sub * 4u + (threadIdx.x >> 6)) * 64u + (threadIdx.x & 63u));
     if (x >= g.w) return;
     const int y0 = (int)seg * g.seg_rows, y1 = y0 + g.seg_rows < g.h ? y0 + g.seg_rows : g.h;
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
-    const bool xin = x >= k && x < g.w - k;                // interior column (server.py:720)
+    const bool in0 = x >= k && x < g.w - k, in1 = x + 1 >= k && x + 1 < g.w - k;   // interior columns (server.py:720)
+    const bool both = in0 && in1;
     int a = x - k;                                         // first byte of the row load, kept inside the row (w >= LB)
     a = a > g.w - LB ? g.w - LB : a;
     a = a < 0 ? 0 : a;
-    const int sh = xin ? 8 * (x - k - a) : 0;              // window bytes start at bit sh of the load
-    const int csh = 8 * (x - a);                           // the centre byte (every column, border ones included)
+    // window byte j (column x - k + j) is byte j + d of the load, d = x - k - a (negative in the row's first lane): byte
+    // selectors for v_perm_b32, 0x0c = constant zero for bytes the load does not hold (never used by an interior pixel)
+    const int d = x - k - a;
+    uint32_t sel[LB / 4];
+#pragma unroll
+    for (int q = 0; q < LB / 4; ++q) {
+        uint32_t sq_ = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sb = 4 * q + j + d;
+            sq_ |= (uint32_t)(sb >= 0 && sb < LB ? sb : 0x0c) << (8 * j);
+        }
+        sel[q] = sq_;
+    }
+    const uint32_t aoff = (uint32_t)a, xoff = (uint32_t)x;
+    const bool even_w = (g.w & 1) == 0;                    // every lane then owns two columns
 
-    typedef typename std::conditional<K <= 3, uint32_t, uint64_t>::type raw_t;
+    struct Raw { uint32_t w[LB / 4]; };
     auto load_row = [&](int t) {                           // walk step t = source row y0 - k + t, clamped into the image
         int yy = y0 - k + t;
         yy = yy < 0 ? 0 : yy > g.h - 1 ? g.h - 1 : yy;
-        raw_t v;
-        __builtin_memcpy(&v, simg + (int64_t)yy * g.s_row + a, LB);
+        const uint8_t* rowp = simg + (int64_t)yy * g.s_row;   // wave-uniform: scalar base + 32-bit lane offset
+        Raw v;
+        __builtin_memcpy(&v, rowp + aoff, LB);
         return v;
     };
-    float f[K][K], rs[K], cen[K];                          // ring of the last K source rows: floats, row sums, centre values
-    auto take = [&](int slot, raw_t v) {
-        cen[slot] = (float)(uint32_t)((v >> csh) & 255u);
-        const raw_t wv = v >> sh;
-        float sum = 0.f;
+    f2 P[K][K], rs[K];                                     // ring of the last K source rows: value pairs, row sums
+    auto take = [&](int slot, const Raw& v) {
+        float fl[K + 1];
+#pragma unroll
+        for (int q = 0; q < LB / 4; ++q) {
+            const uint32_t wv = __builtin_amdgcn_perm(LB == 8 ? v.w[LB / 4 - 1] : 0u, v.w[0], sel[q]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * q + j <= K) fl[4 * q + j] = (float)((wv >> (8 * j)) & 255u);
+        }
+        f2 sum = f2{0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < K; ++c) {
-            f[slot][c] = (float)(uint32_t)((wv >> (8 * c)) & 255u);
-            sum = rn_add(sum, f[slot][c]);                 // integers: exact in any order
+            P[slot][c] = f2{fl[c], fl[c + 1]};             // P[.][k] is the pair of centre values, border columns included
+            sum = sum + P[slot][c];                        // integers: exact in any order
         }
         rs[slot] = sum;
     };
-    constexpr int U = K;                                   // rows of prefetch
-    raw_t nx[U];
+    Raw nx[K];
 #pragma unroll
-    for (int j = 0; j < U; ++j) nx[j] = load_row(j);
+    for (int j = 0; j < K; ++j) nx[j] = load_row(j);
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) {
         take(j, nx[j]);
-        nx[j] = load_row(U + j);
+        nx[j] = load_row(K + j);
     }
     const int nrows = y1 - y0;
     for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += K) {
@@ -220,43 +274,50 @@ __global__ __launch_bounds__(256) void lee_small_kernel(const uint8_t* __restric
             const int t = t0 + u;
             const int slot = (K - 1 + u) % K;              // = t % K
             take(slot, nx[slot]);
-            nx[slot] = load_row(t + U);
+            nx[slot] = load_row(t + K);
             const int yo = t - (K - 1);                    // output row y0 + yo: window rows = ring slots (slot + 1 + r) % K
             if (yo < nrows) {
                 const int y = y0 + yo;
-                float o = cen[(slot + 1 + k) % K];
-                if (xin && y >= k && y < g.h - k) {
-                    float S = 0.f;
+                const f2 c2 = P[(slot + 1 + k) % K][k];
+                f2 o = c2;
+                if (y >= k && y < g.h - k) {               // interior row (wave-uniform)
+                    f2 S = rs[0];
 #pragma unroll
-                    for (int r = 0; r < K; ++r) S = rn_add(S, rs[r]);
-                    const float2 mq = s_tab[(int)S];
-                    const float mean = mq.x;
-                    auto sq = [&](int i) {                 // window value i in row-major order
-                        const float d = rn_sub(f[(slot + 1 + i / K) % K][i % K], mean);
-                        return rn_mul(d, d);
+                    for (int r = 1; r < K; ++r) S = S + rs[r];
+                    const int i0 = (int)S.x, i1 = (int)S.y;
+                    const f2 mean = f2{s_tab[i0], s_tab[i1]}, q = f2{s_tab[NT + i0], s_tab[NT + i1]};
+                    auto sq = [&](int i) {                 // window value i in row-major order, both pixels
+                        const f2 dv = P[(slot + 1 + i / K) % K][i % K] - mean;
+                        return dv * dv;
                     };
-                    float r8[8];
+                    f2 r8[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) r8[j] = sq(j);
 #pragma unroll
                     for (int i = 8; i < n - n % 8; i += 8) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) r8[j] = rn_add(r8[j], sq(i + j));
+                        for (int j = 0; j < 8; ++j) r8[j] = r8[j] + sq(i + j);
                     }
-                    float res = rn_add(rn_add(rn_add(r8[0], r8[1]), rn_add(r8[2], r8[3])),
-                                       rn_add(rn_add(r8[4], r8[5]), rn_add(r8[6], r8[7])));
+                    f2 res = ((r8[0] + r8[1]) + (r8[2] + r8[3])) + ((r8[4] + r8[5]) + (r8[6] + r8[7]));
 #pragma unroll
-                    for (int i = n - n % 8; i < n; ++i) res = rn_add(res, sq(i));
-                    const float var = rn_div(res, fn);
-                    if (var > 0.f) {
-                        const float k_lee = rn_div(var, rn_add(var, mq.y));
-                        o = rn_add(mean, rn_mul(k_lee, rn_sub(o, mean)));
-                    } else {
-                        o = mean;
-                    }
-                    o = o < 0.f ? 0.f : o > 255.f ? 255.f : o;
+                    for (int i = n - n % 8; i < n; ++i) res = res + sq(i);
+                    const f2 var = div_by_const(res, fn, cn);
+                    // var == 0 needs no branch: k_lee = 0 / q = 0 and mean + 0 * (c - mean) = mean, the reference's other arm.
+                    // np.clip needs no code either: 0 <= k_lee <= 1 and every rounding is monotonic, so the result lies
+                    // between mean and the centre value (within a rounding of it), i.e. in [0, 256) and truncates the same
+                    const f2 kl = div_safe_range(var, var + q);
+                    const f2 lee = mean + kl * (c2 - mean);
+                    if (both) o = lee;
+                    else o = f2{in0 ? lee.x : c2.x, in1 ? lee.y : c2.y};
                 }
-                dimg[(int64_t)y * g.d_row + x] = (uint8_t)(uint32_t)o;
+                uint8_t* dp = dimg + (int64_t)y * g.d_row;  // wave-uniform
+                const uint32_t b0 = (uint32_t)o.x, b1 = (uint32_t)o.y;
+                if (even_w || x + 1 < g.w) {
+                    const uint16_t two = (uint16_t)(b0 | (b1 << 8));
+                    __builtin_memcpy(dp + xoff, &two, 2);
+                } else {
+                    dp[xoff] = (uint8_t)b0;
+                }
             }
         }
     }
@@ -278,7 +339,7 @@ extern "C" int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst,
         LeeSmallGeom sg;
         sg.h = h; sg.w = w;
         sg.s_row = src_row_stride; sg.s_img = src_img_stride; sg.d_row = dst_row_stride; sg.d_img = dst_img_stride;
-        sg.nstrips = (w + 63) / 64;
+        sg.nstrips = (w + 127) / 128;
         sg.blocks_per_seg = (sg.nstrips + 3) / 4;
         // segments: enough blocks for a few rounds over the chip, but long enough to amortise the table and the warm-up rows
         int segs = (int)((8192 + (int64_t)sg.blocks_per_seg * n - 1) / ((int64_t)sg.blocks_per_seg * n));
@@ -288,7 +349,7 @@ extern "C" int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst,
         sg.nsegs = (h + sg.seg_rows - 1) / sg.seg_rows;
         const uint64_t nb = (uint64_t)n * sg.nsegs * sg.blocks_per_seg;
         if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many blocks", fn);
-        const size_t lds = (size_t)(255 * (2 * kk + 1) * (2 * kk + 1) + 1) * sizeof(float2);
+        const size_t lds = (size_t)(255 * (2 * kk + 1) * (2 * kk + 1) + 1) * 2 * sizeof(float);
         if (kk == 1) hipLaunchKernelGGL(lee_small_kernel<3>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
         else hipLaunchKernelGGL(lee_small_kernel<5>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
         IPX_LAUNCH_CHECK("lee_small_kernel");

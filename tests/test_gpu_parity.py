@@ -525,7 +525,11 @@ def test_full_size_rank_and_lee_filters(dev):
 
     for k in (3, 5, 9, 11, 31):
         check(host(ops.median_blur(t, k)), lambda a: O.median_blur_u8(a, k), k // 2, True)
-    for wnd in (5, 31):                                     # Lee copies the border band: only interior crops are comparable
+    hd = np.clip(rng.normal(110, 50, (1080, 1920)), 0, 255).astype(np.uint8)   # every pixel of a 1080p frame: 2 M windows each
+    hd[300:500, 200:1500] = (hd[300:500, 200:1500] // 64) * 64               # few levels: tiny and zero variances
+    for wnd in (3, 5):
+        np.testing.assert_array_equal(host(ops.lee_filter(dev_t(hd, dev), wnd)), O.lee_filter_u8(hd, wnd), err_msg=f"lee {wnd}")
+    for wnd in (3, 5, 31):                                  # Lee copies the border band: only interior crops are comparable
         got = host(ops.lee_filter(t, wnd))
         check(got, lambda a: O.lee_filter_u8(a, wnd), wnd // 2 + wnd // 2, False)
         np.testing.assert_array_equal(got[:wnd // 2], img[:wnd // 2])

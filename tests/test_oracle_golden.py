@@ -249,3 +249,39 @@ def test_gauss_taps_are_far_from_rounding_ties_for_every_k():
         assert lib.ipx_gauss_kernel_q8(k, C.c_double(0.0), out.ctypes.data) == 0
         assert out.tolist() == taps, k
         assert min(taps) >= 0 and sum(taps) == 256
+
+
+def test_markstein_division_by_window_size(tmp_path):
+    """ipx_lee.hip divides the variance sum by n = 9 / 25 with y = fl(a c), r = fma(-n, y, a), q = fma(r, c, y), c = fl(1 / n).
+    The three steps scale exactly with powers of two, so correct rounding for all 2^23 significands of three binades (and a
+    strided sample of fifty more) is correct rounding for every float whose quotient is normal.  Plain C, gcc, no GPU."""
+    import shutil, subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    src = tmp_path / "mk.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+int main(void) {
+    const int ns[] = {9, 25, 49};
+    long bad = 0;
+    for (int ni = 0; ni < 3; ++ni) {
+        const float n = (float)ns[ni], c = 1.0f / n;
+        for (int e = 90; e <= 150; ++e) {
+            const uint32_t step = (e >= 126 && e <= 128) ? 1u : 4099u;
+            for (uint32_t m = 0; m < (1u << 23); m += step) {
+                uint32_t bits = ((uint32_t)e << 23) | m; float a; memcpy(&a, &bits, 4);
+                const float y = a * c, r = fmaf(-n, y, a), q = fmaf(r, c, y);
+                if (q != a / n) ++bad;
+            }
+        }
+    }
+    printf("%ld\n", bad);
+    return 0;
+}
+""")
+    exe = tmp_path / "mk"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"], check=True)
+    assert subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip() == "0"
