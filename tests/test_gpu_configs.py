@@ -1,5 +1,8 @@
-"""BASELINE.json configs[2], configs[3], configs[4] at their REAL shapes on one MI355X, through the C ABI, against the
+"""BASELINE.json configs[0] ... configs[4] at their REAL shapes on one MI355X, through the C ABI, against the
 C / numpy oracle (exact equality; all of it is integer / table arithmetic).
+
+configs[0]: one 512 x 512 RGB image: grayscale + 3x3 box blur + histogram equalization (the reference's CPU-runnable case)
+configs[1]: one 3840 x 2160 RGB image: 5x5 Gaussian + Sobel + hist-eq (the bench workload, here as ONE image per launch)
 
 configs[2]: batch of 1080 x 1920 RGB frames, full filter pipeline (server.py:360-388, 443-467, 245-246, 263-277, 428)
 configs[3]: one 4320 x 7680 RGB frame, separable Gaussian k = 15 and 31 (server.py:428 arithmetic per channel)
@@ -37,6 +40,34 @@ def _oracle_full_pipeline(bgr):
             "negative": O.negative_u8(gray), "threshold": O.threshold_u8(gray, 128), "gamma": O.gamma_u8(gray, 0.6),
             "log": O.log_u8(gray, 2.0), "piecewise": O.piecewise_u8(gray, 70, 10, 180, 245),
             "sharpening": CO.laplacian_sharpen_u8(bgr), "gaussian5": CO.gaussian_blur_u8(bgr, 5)}
+
+
+def test_configs0_512_rgb_gray_box_equalize(dev):
+    bgr = _frames(1, 512, 512, 10)[0]
+    t = torch.from_numpy(bgr).to(dev)
+    gray = ops.bgr2gray(t)
+    want_gray = CO.bgr2gray_u8(bgr)
+    np.testing.assert_array_equal(gray.cpu().numpy(), want_gray)
+    np.testing.assert_array_equal(ops.box3(gray).cpu().numpy(), CO.box3_u8(want_gray))
+    np.testing.assert_array_equal(ops.box3(t).cpu().numpy(), CO.box3_u8(bgr))
+    np.testing.assert_array_equal(ops.equalize_hist(gray).cpu().numpy(), CO.equalize_hist_u8(want_gray))
+    g2, eq = ops.bgr2gray_equalize(t)
+    np.testing.assert_array_equal(g2.cpu().numpy(), want_gray)
+    np.testing.assert_array_equal(eq.cpu().numpy(), CO.equalize_hist_u8(want_gray))
+
+
+def test_configs1_single_4k_rgb_gaussian_sobel_equalize(dev):
+    """The bench step on the literal configs[1] input: ONE 3840 x 2160 RGB image, every pixel against the C oracle."""
+    bgr = _frames(1, 2160, 3840, 11)[0]
+    t = torch.from_numpy(bgr).to(dev)
+    np.testing.assert_array_equal(ops.gaussian_blur(t, 5).cpu().numpy(), CO.gaussian_blur_u8(bgr, 5))
+    want_gray = CO.bgr2gray_u8(bgr)
+    g2, eq = ops.bgr2gray_equalize(t)
+    np.testing.assert_array_equal(g2.cpu().numpy(), want_gray)
+    np.testing.assert_array_equal(eq.cpu().numpy(), CO.equalize_hist_u8(want_gray))
+    gray = ops.bgr2gray(t)
+    np.testing.assert_array_equal(ops.sobel(gray).cpu().numpy(), CO.sobel_u8(want_gray))
+    np.testing.assert_array_equal(ops.sobel(t).cpu().numpy(), CO.sobel_u8(bgr))
 
 
 def test_configs2_full_pipeline_1080p_batch(dev):
