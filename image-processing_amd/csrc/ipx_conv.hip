@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "ipx_fields.h"
+#include <atomic>
 
 extern "C" int ipx_lut_u8(void*, const uint8_t*, uint8_t*, int, int, int, int, int64_t, int64_t, int64_t, int64_t, const uint8_t*);
 
@@ -528,6 +529,119 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void sep_pow2_kernel(const 
     }
 }
 
+// ---- the same packed filter on BAND tiles staged in LDS --------------------------------------------------------------
+// Long-lived waves that each stream their own rows reach 5.2-5.6 TB/s on this part, short-lived blocks that load a
+// contiguous band up front 5.9 (scripts/dev/bandbench.hip; a flat copy 6.2).  A block takes band_rows output rows x 4 KiB
+// of row bytes: its (band_rows + 2R) x (4 KiB + 64) source bytes go straight from global memory into LDS (LDS-DMA, 1 KiB
+// per wave instruction, nothing staged in registers), one barrier, then every lane walks its 16-byte column of the tile
+// with the register ring of sep_pow2_kernel, reading rows from LDS.  Rows must be a multiple of 16 bytes (every lane
+// aligned in LDS); other shapes take the strip walker.
+struct BandGeom { ConvGeom g; int band_rows, nbands, ntx; unsigned nblocks; };
+
+template <int C, int K, int kBandLanes>
+__global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                   BandGeom bg, Pow2Taps t)
+{
+    constexpr int R = K / 2, kBandPitch = kBandLanes * 16 + 64;
+    typedef Win<C, R> WR;
+    constexpr int HD = WR::HD;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];
+    const ConvGeom& g = bg.g;
+    const unsigned blk = xcd_remap(blockIdx.x, bg.nblocks);
+    const int xt = (int)(blk % (unsigned)bg.ntx);
+    const unsigned rest = blk / (unsigned)bg.ntx;
+    const int band = (int)(rest % (unsigned)bg.nbands);
+    const unsigned img = rest / (unsigned)bg.nbands;
+    const int y0 = band * bg.band_rows, y1 = y0 + bg.band_rows < g.h ? y0 + bg.band_rows : g.h;
+    const int rows_in = y1 - y0 + 2 * R;
+    const int lane0 = xt * kBandLanes;
+    const int xs = 16 * lane0 - 32 > 0 ? 16 * lane0 - 32 : 0;                // tile = row bytes [xs, xe), both multiples of 16
+    const int xe = 16 * (lane0 + kBandLanes) + 32 < g.L ? 16 * (lane0 + kBandLanes) + 32 : g.L;
+    const int nch = (xe - xs) >> 4;                                          // 16-byte chunks per tile row (<= 260)
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    const int wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+
+    for (int r = wave; r < rows_in; r += kBandLanes / 64) {                  // wave w stages tile rows w, w + 4, ...
+        const uint8_t* rp = row_ptr(g, simg, y0 - R + r, R) + xs;
+        for (int c0 = 0; c0 < nch; c0 += 64) {
+            if (c0 + lane < nch)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(rp + 16 * (c0 + lane)),
+                                                 (void __attribute__((address_space(3)))*)(s_tile + r * kBandPitch + 16 * c0), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int gl = lane0 + (int)threadIdx.x;
+    if (gl >= g.nlanes) return;
+    const int b0 = 16 * gl;
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const int off = b0 - xs;                                                 // the lane's 16 bytes inside a tile row
+    const int lo = (b0 >= 4 * HD ? b0 - 4 * HD : b0) - xs;                   // halo dwords, redirected inside the row at its ends
+    const int hi = (b0 + 16 + 4 * HD <= g.L ? b0 + 16 : b0 + 16 - 4 * HD) - xs;
+    const unsigned short kx1 = (unsigned short)t.kx1, kx2 = (unsigned short)t.kx2;
+    const unsigned short ky1 = (unsigned short)t.ky1, ky2 = (unsigned short)t.ky2;
+    const us2 rnd = {(unsigned short)t.rnd, (unsigned short)t.rnd};
+    const us2 sh = {(unsigned short)t.sh, (unsigned short)t.sh};
+
+    us2 hb[K][8];
+    auto hrow = [&](us2 (&h)[8], int r) {                                    // row pass of tile row r
+        const uint8_t* tr = s_tile + r * kBandPitch;
+        WR W;
+        const u32x4 c = *(const u32x4*)(tr + off);
+        __builtin_memcpy(&W.w[HD], &c, 16);
+#pragma unroll
+        for (int i = 0; i < HD; ++i) {
+            W.w[i] = *(const uint32_t*)(tr + lo + 4 * i);
+            W.w[HD + 4 + i] = *(const uint32_t*)(tr + hi + 4 * i);
+        }
+        fix_edges<C, R>(W, first, last);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int p = slot_p(s);
+            if (K == 3) {
+                h[s] = (fld<C, R>(W, p - C) + fld<C, R>(W, p + C)) + fld<C, R>(W, p) * kx1;
+            } else {
+                const us2 o = fld<C, R>(W, p - 2 * C) + fld<C, R>(W, p + 2 * C);
+                const us2 i = fld<C, R>(W, p - C) + fld<C, R>(W, p + C);
+                h[s] = (o + i * kx1) + fld<C, R>(W, p) * kx2;
+            }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) hrow(hb[j], j);
+    const int nrows = y1 - y0;
+    for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += K) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const int tt = t0 + q;
+            const int slot = (K - 1 + q) % K;                                // = tt % K
+            const int yo = tt - (K - 1);
+            if (yo < nrows) {
+                hrow(hb[slot], tt);
+                us2 o[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    us2 v;
+                    if (K == 3) {
+                        v = (hb[(slot + 1) % K][s] + hb[slot][s]) + (hb[(slot + 2) % K][s] * ky1 + rnd);
+                    } else {
+                        const us2 oo = hb[(slot + 1) % K][s] + hb[slot][s];
+                        const us2 ii = hb[(slot + 2) % K][s] + hb[(slot + 4) % K][s];
+                        v = (oo + ii * ky1) + (hb[(slot + 3) % K][s] * ky2 + rnd);
+                    }
+                    o[s] = v >> sh;
+                }
+                u32x4 ov;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ov[k] = pack_fields(o[2 * k], o[2 * k + 1]);
+                st16_nt(dimg + (int64_t)(y0 + yo) * g.d_row + b0, ov);
+            }
+        }
+    }
+}
+
 // ---- erode / dilate with a small structuring element (cv2.erode / cv2.dilate, server.py:433-434) -------------------
 // Same strip walker, gray images.  A structuring element of K x K (K = 3 or 5) whose non-empty rows use at most two
 // distinct column masks (every rectangle, cross and OpenCV ellipse of that size does): per source row each lane forms,
@@ -923,6 +1037,33 @@ void launch_sep_pow2(hipStream_t st, const uint8_t* src, uint8_t* dst, const Con
     }
 }
 
+template <int K, int LN>
+int launch_sep_pow2_band(hipStream_t st, const uint8_t* src, uint8_t* dst, const ConvGeom& g, int n, int c, const Pow2Taps& t, int band_rows)
+{
+    BandGeom bg;
+    bg.g = g;
+    bg.band_rows = band_rows;
+    bg.nbands = (g.h + band_rows - 1) / band_rows;
+    bg.ntx = (g.nlanes + LN - 1) / LN;
+    const uint64_t nb = (uint64_t)n * bg.nbands * bg.ntx;
+    if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "ipx_sep_filter_q8_u8: too many tiles");
+    bg.nblocks = (unsigned)nb;
+    const size_t lds = (size_t)(band_rows + 2 * (K / 2)) * (LN * 16 + 64);
+    auto go = [&](auto kern) {
+        static std::atomic<bool> raised{false};                       // tiles above 64 KiB need the limit raised once per kernel
+        if (lds > 64 * 1024 && !raised.exchange(true))
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3(bg.nblocks), dim3(LN), lds, st, src, dst, bg, t);
+    };
+    switch (c) {
+        case 1: go(sep_pow2_band_kernel<1, K, LN>); break;
+        case 2: go(sep_pow2_band_kernel<2, K, LN>); break;
+        case 3: go(sep_pow2_band_kernel<3, K, LN>); break;
+        default: go(sep_pow2_band_kernel<4, K, LN>); break;
+    }
+    return IPX_OK;
+}
+
 }  // namespace
 
 // Called by ipx_morph_u8 (ipx_rank.hip) for structuring elements the strip walker handles: returns 1 if it launched,
@@ -1027,6 +1168,19 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
         && !getenv("IPX_NO_POW2")                                     // A/B switch of development builds
 #endif
     ) {                                                               // cv2.GaussianBlur's own 3- and 5-tap kernels
+        // rows of whole 16-byte lanes, at least one full 4 KiB tile wide: LDS band tiles (5-10 % faster than the strip
+        // walker on BGR frames: 229 vs 248 us for 5 taps, 206 vs 232 us for 3 taps per 24 x 4K, scripts/dev/bandab.py)
+        int band = g.L % 16 == 0 && g.nlanes >= 256 ? 12 : 0;
+#ifdef IPX_DEV
+        band = env_int("IPX_BAND_ROWS", band);                        // development: A/B (0 = strip walker)
+        if (g.L % 16) band = 0;
+#endif
+        if (band > 0) {
+            if (int rc = k == 3 ? launch_sep_pow2_band<3, 256>(st, src, dst, g, n, c, pt, band)
+                                : launch_sep_pow2_band<5, 256>(st, src, dst, g, n, c, pt, band)) return rc;
+            IPX_LAUNCH_CHECK("sep_pow2_band_kernel");
+            return IPX_OK;
+        }
         if (k == 3) launch_sep_pow2<3>(st, src, dst, g, c, pt);
         else launch_sep_pow2<5>(st, src, dst, g, c, pt);
         IPX_LAUNCH_CHECK("sep_pow2_kernel");

@@ -221,6 +221,36 @@ def test_gaussian_power_of_two_symmetric_taps(dev):
                                                   O.sep_filter_q8_u8(img, kx, ky), err_msg=f"{full} {kx} {ky}")
 
 
+def test_gaussian_band_tiles(dev):
+    """rows that are a multiple of 16 bytes and at least 4 KiB long take the LDS band-tile kernel for cv2's 3- and 5-tap
+    Gaussians: tile edges (a second tile of 2 lanes, exactly one tile, three tiles), heights around the 12-row bands,
+    every channel count, 0 / 255 images, a strided batch with an unaligned base, and row blocks with halo rows."""
+    rng = np.random.default_rng(55)
+    for cn, w in ((1, 4096), (1, 4128), (2, 2064), (3, 1376), (4, 1032), (3, 3840), (1, 8192 + 16)):
+        for h in (1, 2, 5, 12, 13, 23, 24, 25, 40):
+            full = (h, w) + ((cn,) if cn > 1 else ())
+            img = rng.integers(0, 256, full, dtype=np.uint8) if h != 13 else np.where(rng.random(full) < 0.5, 0, 255).astype(np.uint8)
+            for k in (3, 5):
+                np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(img, dev), k)), O.gaussian_blur_u8(img, k), err_msg=f"{full} k={k}")
+    big = rng.integers(0, 256, (3, 40, 1400 * 3 + 9), dtype=np.uint8)
+    view = dev_t(big, dev)[:, 3:38, 5:5 + 1376 * 3].unflatten(2, (1376, 3))      # strided batch, unaligned base, L = 4128
+    ref_in = big[:, 3:38, 5:5 + 1376 * 3].reshape(3, 35, 1376, 3)
+    for k in (3, 5):
+        got = host(ops.gaussian_blur(view, k))
+        for i in range(3):
+            np.testing.assert_array_equal(got[i], O.gaussian_blur_u8(ref_in[i], k))
+    img = rng.integers(0, 256, (60, 1376, 3), dtype=np.uint8)                   # a row block with halo rows == the whole image cropped
+    t = dev_t(img, dev)
+    for k in (3, 5):
+        r = k // 2
+        want = O.gaussian_blur_u8(img, k)
+        for y0, y1 in ((0, 17), (17, 43), (43, 60), (30, 31)):
+            top = t[y0 - r:y0] if y0 > 0 else None
+            bot = t[y1:y1 + r] if y1 < 60 else None
+            got = host(ops.gaussian_blur(t[y0:y1], k, top_halo=top, bottom_halo=bot))
+            np.testing.assert_array_equal(got, want[y0:y1], err_msg=f"rows {y0}:{y1} k={k}")
+
+
 def test_gaussian_max_values_do_not_overflow(dev):
     img = np.full((40, 1200, 3), 255, np.uint8)
     for k in (3, 5, 7, 15, 31):
