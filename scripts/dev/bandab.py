@@ -19,9 +19,12 @@ def pipe_time(fn, reps=10):
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in ev)
     return round(ts[len(ts) // 2] * 1e3, 1)
-os.environ.pop("IPX_BAND_ROWS", None)
+for _ in range(300):                                   # warm the chip up: the first measurements of a process read 10-20 % high
+    ops.gaussian_blur(bgr, 5); ops.sobel(gray)
+torch.cuda.synchronize()
+os.environ["IPX_BAND_ROWS"] = "0"
 ref5, ref3, refg = ops.gaussian_blur(bgr, 5).clone(), ops.gaussian_blur(bgr, 3).clone(), ops.gaussian_blur(gray, 5).clone()
-print("walker: g5 bgr", pipe_time(lambda: ops.gaussian_blur(bgr, 5)), "g3 bgr", pipe_time(lambda: ops.gaussian_blur(bgr, 3)), "g5 gray", pipe_time(lambda: ops.gaussian_blur(gray, 5)), flush=True)
+for _rep in range(2): print("walker: g5 bgr", pipe_time(lambda: ops.gaussian_blur(bgr, 5)), "g3 bgr", pipe_time(lambda: ops.gaussian_blur(bgr, 3)), "g5 gray", pipe_time(lambda: ops.gaussian_blur(gray, 5)), flush=True)
 for rows in [int(x) for x in os.environ.get("ROWS", "8,11,12,16,20,24,32").split(",")]:
     os.environ["IPX_BAND_ROWS"] = str(rows)
     ok = bool((ops.gaussian_blur(bgr, 5) == ref5).all()) and bool((ops.gaussian_blur(bgr, 3) == ref3).all()) and bool((ops.gaussian_blur(gray, 5) == refg).all())
