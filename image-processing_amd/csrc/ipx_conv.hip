@@ -537,33 +537,36 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void sep_pow2_kernel(const 
 // with the register ring of sep_pow2_kernel, reading rows from LDS.  Rows must be a multiple of 16 bytes (every lane
 // aligned in LDS); other shapes take the strip walker.
 struct BandGeom { ConvGeom g; int band_rows, nbands, ntx; unsigned nblocks; };
+constexpr int kBandLanes = 256, kBandPitch = kBandLanes * 16 + 64;
 
-template <int C, int K, int kBandLanes>
-__global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                                   BandGeom bg, Pow2Taps t)
+struct BandTile {                                          // what a block of a band kernel works on (all wave-uniform)
+    unsigned img;
+    int y0, y1, rows_in;                                   // output rows [y0, y1), rows_in = y1 - y0 + 2R tile rows
+    int lane0, xs;                                         // first 16-byte lane, first row byte held by the tile
+};
+
+// Decode the block's tile and stage its source bytes in LDS (LDS-DMA, 1 KiB per wave instruction); returns after the barrier.
+template <int R>
+__device__ __forceinline__ BandTile band_stage(const BandGeom& bg, const uint8_t* __restrict__ src, uint8_t* s_tile)
 {
-    constexpr int R = K / 2, kBandPitch = kBandLanes * 16 + 64;
-    typedef Win<C, R> WR;
-    constexpr int HD = WR::HD;
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];
     const ConvGeom& g = bg.g;
+    BandTile t;
     const unsigned blk = xcd_remap(blockIdx.x, bg.nblocks);
     const int xt = (int)(blk % (unsigned)bg.ntx);
     const unsigned rest = blk / (unsigned)bg.ntx;
     const int band = (int)(rest % (unsigned)bg.nbands);
-    const unsigned img = rest / (unsigned)bg.nbands;
-    const int y0 = band * bg.band_rows, y1 = y0 + bg.band_rows < g.h ? y0 + bg.band_rows : g.h;
-    const int rows_in = y1 - y0 + 2 * R;
-    const int lane0 = xt * kBandLanes;
-    const int xs = 16 * lane0 - 32 > 0 ? 16 * lane0 - 32 : 0;                // tile = row bytes [xs, xe), both multiples of 16
-    const int xe = 16 * (lane0 + kBandLanes) + 32 < g.L ? 16 * (lane0 + kBandLanes) + 32 : g.L;
-    const int nch = (xe - xs) >> 4;                                          // 16-byte chunks per tile row (<= 260)
-    const uint8_t* simg = src + (int64_t)img * g.s_img;
-    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    t.img = rest / (unsigned)bg.nbands;
+    t.y0 = band * bg.band_rows;
+    t.y1 = t.y0 + bg.band_rows < g.h ? t.y0 + bg.band_rows : g.h;
+    t.rows_in = t.y1 - t.y0 + 2 * R;
+    t.lane0 = xt * kBandLanes;
+    t.xs = 16 * t.lane0 - 32 > 0 ? 16 * t.lane0 - 32 : 0;                    // tile = row bytes [xs, xe), both multiples of 16
+    const int xe = 16 * (t.lane0 + kBandLanes) + 32 < g.L ? 16 * (t.lane0 + kBandLanes) + 32 : g.L;
+    const int nch = (xe - t.xs) >> 4;                                        // 16-byte chunks per tile row (<= 260)
+    const uint8_t* simg = src + (int64_t)t.img * g.s_img;
     const int wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-
-    for (int r = wave; r < rows_in; r += kBandLanes / 64) {                  // wave w stages tile rows w, w + 4, ...
-        const uint8_t* rp = row_ptr(g, simg, y0 - R + r, R) + xs;
+    for (int r = wave; r < t.rows_in; r += kBandLanes / 64) {                // wave w stages tile rows w, w + 4, ...
+        const uint8_t* rp = row_ptr(g, simg, t.y0 - R + r, R) + t.xs;
         for (int c0 = 0; c0 < nch; c0 += 64) {
             if (c0 + lane < nch)
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(rp + 16 * (c0 + lane)),
@@ -572,14 +575,42 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    return t;
+}
 
-    const int gl = lane0 + (int)threadIdx.x;
+// A lane's window of tile row r: its 16 bytes at `off`, halo dwords at `lo` / `hi` (redirected inside the row at its ends)
+template <int C, int R>
+__device__ __forceinline__ void band_win(Win<C, R>& W, const uint8_t* s_tile, int r, int off, int lo, int hi)
+{
+    constexpr int HD = Win<C, R>::HD;
+    const uint8_t* tr = s_tile + r * kBandPitch;
+    const u32x4 c = *(const u32x4*)(tr + off);
+    __builtin_memcpy(&W.w[HD], &c, 16);
+#pragma unroll
+    for (int i = 0; i < HD; ++i) {
+        W.w[i] = *(const uint32_t*)(tr + lo + 4 * i);
+        W.w[HD + 4 + i] = *(const uint32_t*)(tr + hi + 4 * i);
+    }
+}
+
+template <int C, int K>
+__global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                   BandGeom bg, Pow2Taps t)
+{
+    constexpr int R = K / 2;
+    typedef Win<C, R> WR;
+    constexpr int HD = WR::HD;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];
+    const ConvGeom& g = bg.g;
+    const BandTile bt = band_stage<R>(bg, src, s_tile);
+    const int gl = bt.lane0 + (int)threadIdx.x;
     if (gl >= g.nlanes) return;
     const int b0 = 16 * gl;
     const bool first = b0 == 0, last = b0 + 16 == g.L;
-    const int off = b0 - xs;                                                 // the lane's 16 bytes inside a tile row
-    const int lo = (b0 >= 4 * HD ? b0 - 4 * HD : b0) - xs;                   // halo dwords, redirected inside the row at its ends
-    const int hi = (b0 + 16 + 4 * HD <= g.L ? b0 + 16 : b0 + 16 - 4 * HD) - xs;
+    const int off = b0 - bt.xs;
+    const int lo = (b0 >= 4 * HD ? b0 - 4 * HD : b0) - bt.xs;
+    const int hi = (b0 + 16 + 4 * HD <= g.L ? b0 + 16 : b0 + 16 - 4 * HD) - bt.xs;
+    uint8_t* dimg = dst + (int64_t)bt.img * g.d_img;
     const unsigned short kx1 = (unsigned short)t.kx1, kx2 = (unsigned short)t.kx2;
     const unsigned short ky1 = (unsigned short)t.ky1, ky2 = (unsigned short)t.ky2;
     const us2 rnd = {(unsigned short)t.rnd, (unsigned short)t.rnd};
@@ -587,15 +618,8 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
 
     us2 hb[K][8];
     auto hrow = [&](us2 (&h)[8], int r) {                                    // row pass of tile row r
-        const uint8_t* tr = s_tile + r * kBandPitch;
         WR W;
-        const u32x4 c = *(const u32x4*)(tr + off);
-        __builtin_memcpy(&W.w[HD], &c, 16);
-#pragma unroll
-        for (int i = 0; i < HD; ++i) {
-            W.w[i] = *(const uint32_t*)(tr + lo + 4 * i);
-            W.w[HD + 4 + i] = *(const uint32_t*)(tr + hi + 4 * i);
-        }
+        band_win<C, R>(W, s_tile, r, off, lo, hi);
         fix_edges<C, R>(W, first, last);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -611,7 +635,7 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
     };
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) hrow(hb[j], j);
-    const int nrows = y1 - y0;
+    const int nrows = bt.y1 - bt.y0;
     for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += K) {
 #pragma unroll
         for (int q = 0; q < K; ++q) {
@@ -636,7 +660,47 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
                 u32x4 ov;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) ov[k] = pack_fields(o[2 * k], o[2 * k + 1]);
-                st16_nt(dimg + (int64_t)(y0 + yo) * g.d_row + b0, ov);
+                st16_nt(dimg + (int64_t)(bt.y0 + yo) * g.d_row + b0, ov);
+            }
+        }
+    }
+}
+
+// The 3 x 3 operators on the same band tiles (sharpen / box / Sobel on BGR frames: rows of >= 4 KiB).
+template <int OP, int C>
+__global__ __launch_bounds__(kBandLanes) void conv3_band_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, BandGeom bg)
+{
+    typedef Win<C, 1> W1;
+    typedef Conv3<OP, C> Op;
+    constexpr int HD = W1::HD;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];
+    const ConvGeom& g = bg.g;
+    const BandTile bt = band_stage<1>(bg, src, s_tile);
+    const int gl = bt.lane0 + (int)threadIdx.x;
+    if (gl >= g.nlanes) return;
+    const int b0 = 16 * gl;
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const int off = b0 - bt.xs;
+    const int lo = (b0 >= 4 * HD ? b0 - 4 * HD : b0) - bt.xs;
+    const int hi = (b0 + 16 + 4 * HD <= g.L ? b0 + 16 : b0 + 16 - 4 * HD) - bt.xs;
+    uint8_t* dimg = dst + (int64_t)bt.img * g.d_img;
+    typename Op::Feat f[3];
+    auto frow = [&](typename Op::Feat& ft, int r) {
+        W1 W;
+        band_win<C, 1>(W, s_tile, r, off, lo, hi);
+        fix_edges<C, 1>(W, first, last);
+        Op::feat(ft, W);
+    };
+    frow(f[0], 0);
+    frow(f[1], 1);
+    const int nrows = bt.y1 - bt.y0;
+    for (int t0 = 2; t0 - 2 < nrows; t0 += 3) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int tt = t0 + q, slot = (2 + q) % 3, yo = tt - 2;
+            if (yo < nrows) {
+                frow(f[slot], tt);
+                st16_nt(dimg + (int64_t)(bt.y0 + yo) * g.d_row + b0, Op::out(f[(slot + 1) % 3], f[(slot + 2) % 3], f[slot]));
             }
         }
     }
@@ -958,6 +1022,9 @@ unsigned conv_block(const ConvGeom& g) { return 64u * (unsigned)g.wpb; }
 unsigned conv_grid(const ConvGeom& g) { return g.main_blocks + (g.border_total + conv_block(g) - 1) / conv_block(g); }
 
 template <int OP>
+int launch_conv3_band(hipStream_t st, const uint8_t* src, uint8_t* dst, const ConvGeom& g, int n, int c, int band_rows);
+
+template <int OP>
 int launch_conv3(const char* fn, void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
                  int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* top, const uint8_t* bot)
 {
@@ -965,6 +1032,17 @@ int launch_conv3(const char* fn, void* stream, const uint8_t* src, uint8_t* dst,
     if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, c, 1, kMaxWavesPerBlock, kConv3U, s_row, s_img, d_row, d_img, top, bot)) return rc;
     const dim3 grid(conv_grid(g)), block(conv_block(g));
     hipStream_t st = (hipStream_t)stream;
+    // rows of whole 16-byte lanes, at least one full 4 KiB tile wide (BGR frames): LDS band tiles, as for the Gaussian
+    int band = g.L % 16 == 0 && g.nlanes >= 256 ? 8 : 0;
+#ifdef IPX_DEV
+    band = env_int("IPX_BAND3_ROWS", band);                           // development: A/B (0 = strip walker)
+    if (g.L % 16) band = 0;
+#endif
+    if (band > 0) {
+        if (int rc = launch_conv3_band<OP>(st, src, dst, g, n, c, band)) return rc;
+        IPX_LAUNCH_CHECK("conv3_band_kernel");
+        return IPX_OK;
+    }
     switch (c) {
         case 1: hipLaunchKernelGGL((conv3_kernel<OP, 1>), grid, block, 0, st, src, dst, g); break;
         case 2: hipLaunchKernelGGL((conv3_kernel<OP, 2>), grid, block, 0, st, src, dst, g); break;
@@ -1037,29 +1115,52 @@ void launch_sep_pow2(hipStream_t st, const uint8_t* src, uint8_t* dst, const Con
     }
 }
 
-template <int K, int LN>
-int launch_sep_pow2_band(hipStream_t st, const uint8_t* src, uint8_t* dst, const ConvGeom& g, int n, int c, const Pow2Taps& t, int band_rows)
+int make_band_geom(BandGeom& bg, const ConvGeom& g, int n, int band_rows)
 {
-    BandGeom bg;
     bg.g = g;
     bg.band_rows = band_rows;
     bg.nbands = (g.h + band_rows - 1) / band_rows;
-    bg.ntx = (g.nlanes + LN - 1) / LN;
+    bg.ntx = (g.nlanes + kBandLanes - 1) / kBandLanes;
     const uint64_t nb = (uint64_t)n * bg.nbands * bg.ntx;
-    if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "ipx_sep_filter_q8_u8: too many tiles");
+    if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "too many band tiles");
     bg.nblocks = (unsigned)nb;
-    const size_t lds = (size_t)(band_rows + 2 * (K / 2)) * (LN * 16 + 64);
-    auto go = [&](auto kern) {
-        static std::atomic<bool> raised{false};                       // tiles above 64 KiB need the limit raised once per kernel
-        if (lds > 64 * 1024 && !raised.exchange(true))
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(kern, dim3(bg.nblocks), dim3(LN), lds, st, src, dst, bg, t);
-    };
+    return IPX_OK;
+}
+
+template <auto kern, class... Args>
+void launch_band(hipStream_t st, const BandGeom& bg, int r, const uint8_t* src, uint8_t* dst, Args... args)
+{
+    const size_t lds = (size_t)(bg.band_rows + 2 * r) * kBandPitch;
+    static std::atomic<bool> raised{false};                       // per kernel (template instance): tiles above 64 KiB need the limit raised once
+    if (lds > 64 * 1024 && !raised.exchange(true))
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3(bg.nblocks), dim3(kBandLanes), lds, st, src, dst, bg, args...);
+}
+
+template <int K>
+int launch_sep_pow2_band(hipStream_t st, const uint8_t* src, uint8_t* dst, const ConvGeom& g, int n, int c, const Pow2Taps& t, int band_rows)
+{
+    BandGeom bg;
+    if (int rc = make_band_geom(bg, g, n, band_rows)) return rc;
     switch (c) {
-        case 1: go(sep_pow2_band_kernel<1, K, LN>); break;
-        case 2: go(sep_pow2_band_kernel<2, K, LN>); break;
-        case 3: go(sep_pow2_band_kernel<3, K, LN>); break;
-        default: go(sep_pow2_band_kernel<4, K, LN>); break;
+        case 1: launch_band<sep_pow2_band_kernel<1, K>>(st, bg, K / 2, src, dst, t); break;
+        case 2: launch_band<sep_pow2_band_kernel<2, K>>(st, bg, K / 2, src, dst, t); break;
+        case 3: launch_band<sep_pow2_band_kernel<3, K>>(st, bg, K / 2, src, dst, t); break;
+        default: launch_band<sep_pow2_band_kernel<4, K>>(st, bg, K / 2, src, dst, t); break;
+    }
+    return IPX_OK;
+}
+
+template <int OP>
+int launch_conv3_band(hipStream_t st, const uint8_t* src, uint8_t* dst, const ConvGeom& g, int n, int c, int band_rows)
+{
+    BandGeom bg;
+    if (int rc = make_band_geom(bg, g, n, band_rows)) return rc;
+    switch (c) {
+        case 1: launch_band<conv3_band_kernel<OP, 1>>(st, bg, 1, src, dst); break;
+        case 2: launch_band<conv3_band_kernel<OP, 2>>(st, bg, 1, src, dst); break;
+        case 3: launch_band<conv3_band_kernel<OP, 3>>(st, bg, 1, src, dst); break;
+        default: launch_band<conv3_band_kernel<OP, 4>>(st, bg, 1, src, dst); break;
     }
     return IPX_OK;
 }
@@ -1170,14 +1271,14 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     ) {                                                               // cv2.GaussianBlur's own 3- and 5-tap kernels
         // rows of whole 16-byte lanes, at least one full 4 KiB tile wide: LDS band tiles (5-10 % faster than the strip
         // walker on BGR frames: 229 vs 248 us for 5 taps, 206 vs 232 us for 3 taps per 24 x 4K, scripts/dev/bandab.py)
-        int band = g.L % 16 == 0 && g.nlanes >= 256 ? 12 : 0;
+        int band = g.L % 16 == 0 && g.nlanes >= 256 ? (k == 3 ? 8 : 12) : 0;   // 3 taps: 3 blocks of 41 KiB per CU; 5 taps: 2 of 66 KiB
 #ifdef IPX_DEV
         band = env_int("IPX_BAND_ROWS", band);                        // development: A/B (0 = strip walker)
         if (g.L % 16) band = 0;
 #endif
         if (band > 0) {
-            if (int rc = k == 3 ? launch_sep_pow2_band<3, 256>(st, src, dst, g, n, c, pt, band)
-                                : launch_sep_pow2_band<5, 256>(st, src, dst, g, n, c, pt, band)) return rc;
+            if (int rc = k == 3 ? launch_sep_pow2_band<3>(st, src, dst, g, n, c, pt, band)
+                                : launch_sep_pow2_band<5>(st, src, dst, g, n, c, pt, band)) return rc;
             IPX_LAUNCH_CHECK("sep_pow2_band_kernel");
             return IPX_OK;
         }

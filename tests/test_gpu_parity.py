@@ -232,6 +232,8 @@ def test_gaussian_band_tiles(dev):
             img = rng.integers(0, 256, full, dtype=np.uint8) if h != 13 else np.where(rng.random(full) < 0.5, 0, 255).astype(np.uint8)
             for k in (3, 5):
                 np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(img, dev), k)), O.gaussian_blur_u8(img, k), err_msg=f"{full} k={k}")
+            for name, ref in CONV:                                     # the 3 x 3 operators take band tiles on the same shapes
+                np.testing.assert_array_equal(host(getattr(ops, name)(dev_t(img, dev))), ref(img), err_msg=f"{full} {name}")
     big = rng.integers(0, 256, (3, 40, 1400 * 3 + 9), dtype=np.uint8)
     view = dev_t(big, dev)[:, 3:38, 5:5 + 1376 * 3].unflatten(2, (1376, 3))      # strided batch, unaligned base, L = 4128
     ref_in = big[:, 3:38, 5:5 + 1376 * 3].reshape(3, 35, 1376, 3)
@@ -239,8 +241,18 @@ def test_gaussian_band_tiles(dev):
         got = host(ops.gaussian_blur(view, k))
         for i in range(3):
             np.testing.assert_array_equal(got[i], O.gaussian_blur_u8(ref_in[i], k))
+    for name, ref in CONV:
+        got = host(getattr(ops, name)(view))
+        for i in range(3):
+            np.testing.assert_array_equal(got[i], ref(ref_in[i]), err_msg=name)
     img = rng.integers(0, 256, (60, 1376, 3), dtype=np.uint8)                   # a row block with halo rows == the whole image cropped
     t = dev_t(img, dev)
+    for name, ref in CONV:
+        want = ref(img)
+        for y0, y1 in ((0, 17), (17, 43), (43, 60), (30, 31)):
+            top = t[y0 - 1:y0] if y0 > 0 else None
+            bot = t[y1:y1 + 1] if y1 < 60 else None
+            np.testing.assert_array_equal(host(getattr(ops, name)(t[y0:y1], top_halo=top, bottom_halo=bot)), want[y0:y1], err_msg=f"{name} rows {y0}:{y1}")
     for k in (3, 5):
         r = k // 2
         want = O.gaussian_blur_u8(img, k)
