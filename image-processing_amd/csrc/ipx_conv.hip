@@ -536,8 +536,8 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void sep_pow2_kernel(const 
 // per wave instruction, nothing staged in registers), one barrier, then every lane walks its 16-byte column of the tile
 // with the register ring of sep_pow2_kernel, reading rows from LDS.  Rows must be a multiple of 16 bytes (every lane
 // aligned in LDS); other shapes take the strip walker.
-struct BandGeom { ConvGeom g; int band_rows, nbands, ntx; unsigned nblocks; };
-constexpr int kBandLanes = 256, kBandPitch = kBandLanes * 16 + 64;
+struct BandGeom { ConvGeom g; int band_rows, nbands, ntx, tile_lanes, pitch; unsigned nblocks; };   // pitch = 16 tile_lanes + 64
+constexpr int kBandLanes = 256;                            // lanes per tile at most (block = tile_lanes rounded up to whole waves)
 
 struct BandTile {                                          // what a block of a band kernel works on (all wave-uniform)
     unsigned img;
@@ -559,18 +559,19 @@ __device__ __forceinline__ BandTile band_stage(const BandGeom& bg, const uint8_t
     t.y0 = band * bg.band_rows;
     t.y1 = t.y0 + bg.band_rows < g.h ? t.y0 + bg.band_rows : g.h;
     t.rows_in = t.y1 - t.y0 + 2 * R;
-    t.lane0 = xt * kBandLanes;
+    t.lane0 = xt * bg.tile_lanes;
     t.xs = 16 * t.lane0 - 32 > 0 ? 16 * t.lane0 - 32 : 0;                    // tile = row bytes [xs, xe), both multiples of 16
-    const int xe = 16 * (t.lane0 + kBandLanes) + 32 < g.L ? 16 * (t.lane0 + kBandLanes) + 32 : g.L;
-    const int nch = (xe - t.xs) >> 4;                                        // 16-byte chunks per tile row (<= 260)
+    const int xe = 16 * (t.lane0 + bg.tile_lanes) + 32 < g.L ? 16 * (t.lane0 + bg.tile_lanes) + 32 : g.L;
+    const int nch = (xe - t.xs) >> 4;                                        // 16-byte chunks per tile row (<= tile_lanes + 4)
     const uint8_t* simg = src + (int64_t)t.img * g.s_img;
     const int wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-    for (int r = wave; r < t.rows_in; r += kBandLanes / 64) {                // wave w stages tile rows w, w + 4, ...
+    const int nwaves = (int)(blockDim.x >> 6);
+    for (int r = wave; r < t.rows_in; r += nwaves) {                         // wave w stages tile rows w, w + #waves, ...
         const uint8_t* rp = row_ptr(g, simg, t.y0 - R + r, R) + t.xs;
         for (int c0 = 0; c0 < nch; c0 += 64) {
             if (c0 + lane < nch)
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(rp + 16 * (c0 + lane)),
-                                                 (void __attribute__((address_space(3)))*)(s_tile + r * kBandPitch + 16 * c0), 16, 0, 0);
+                                                 (void __attribute__((address_space(3)))*)(s_tile + r * bg.pitch + 16 * c0), 16, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -580,10 +581,10 @@ __device__ __forceinline__ BandTile band_stage(const BandGeom& bg, const uint8_t
 
 // A lane's window of tile row r: its 16 bytes at `off`, halo dwords at `lo` / `hi` (redirected inside the row at its ends)
 template <int C, int R>
-__device__ __forceinline__ void band_win(Win<C, R>& W, const uint8_t* s_tile, int r, int off, int lo, int hi)
+__device__ __forceinline__ void band_win(Win<C, R>& W, const uint8_t* s_tile, int pitch, int r, int off, int lo, int hi)
 {
     constexpr int HD = Win<C, R>::HD;
-    const uint8_t* tr = s_tile + r * kBandPitch;
+    const uint8_t* tr = s_tile + r * pitch;
     const u32x4 c = *(const u32x4*)(tr + off);
     __builtin_memcpy(&W.w[HD], &c, 16);
 #pragma unroll
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
     const ConvGeom& g = bg.g;
     const BandTile bt = band_stage<R>(bg, src, s_tile);
     const int gl = bt.lane0 + (int)threadIdx.x;
-    if (gl >= g.nlanes) return;
+    if ((int)threadIdx.x >= bg.tile_lanes || gl >= g.nlanes) return;
     const int b0 = 16 * gl;
     const bool first = b0 == 0, last = b0 + 16 == g.L;
     const int off = b0 - bt.xs;
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
     us2 hb[K][8];
     auto hrow = [&](us2 (&h)[8], int r) {                                    // row pass of tile row r
         WR W;
-        band_win<C, R>(W, s_tile, r, off, lo, hi);
+        band_win<C, R>(W, s_tile, bg.pitch, r, off, lo, hi);
         fix_edges<C, R>(W, first, last);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(kBandLanes) void conv3_band_kernel(const uint8_t* _
     const ConvGeom& g = bg.g;
     const BandTile bt = band_stage<1>(bg, src, s_tile);
     const int gl = bt.lane0 + (int)threadIdx.x;
-    if (gl >= g.nlanes) return;
+    if ((int)threadIdx.x >= bg.tile_lanes || gl >= g.nlanes) return;
     const int b0 = 16 * gl;
     const bool first = b0 == 0, last = b0 + 16 == g.L;
     const int off = b0 - bt.xs;
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(kBandLanes) void conv3_band_kernel(const uint8_t* _
     typename Op::Feat f[3];
     auto frow = [&](typename Op::Feat& ft, int r) {
         W1 W;
-        band_win<C, 1>(W, s_tile, r, off, lo, hi);
+        band_win<C, 1>(W, s_tile, bg.pitch, r, off, lo, hi);
         fix_edges<C, 1>(W, first, last);
         Op::feat(ft, W);
     };
@@ -1121,6 +1122,9 @@ int make_band_geom(BandGeom& bg, const ConvGeom& g, int n, int band_rows)
     bg.band_rows = band_rows;
     bg.nbands = (g.h + band_rows - 1) / band_rows;
     bg.ntx = (g.nlanes + kBandLanes - 1) / kBandLanes;
+    bg.tile_lanes = ((g.nlanes + bg.ntx - 1) / bg.ntx + 63) / 64 * 64;   // near-equal widths in whole waves (1080p BGR: 192 + 168 lanes,
+                                                                  // not 256 + 104; 4K BGR: 256 + 256 + 208)
+    bg.pitch = 16 * bg.tile_lanes + 64;
     const uint64_t nb = (uint64_t)n * bg.nbands * bg.ntx;
     if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "too many band tiles");
     bg.nblocks = (unsigned)nb;
@@ -1130,11 +1134,11 @@ int make_band_geom(BandGeom& bg, const ConvGeom& g, int n, int band_rows)
 template <auto kern, class... Args>
 void launch_band(hipStream_t st, const BandGeom& bg, int r, const uint8_t* src, uint8_t* dst, Args... args)
 {
-    const size_t lds = (size_t)(bg.band_rows + 2 * r) * kBandPitch;
+    const size_t lds = (size_t)(bg.band_rows + 2 * r) * bg.pitch;
     static std::atomic<bool> raised{false};                       // per kernel (template instance): tiles above 64 KiB need the limit raised once
     if (lds > 64 * 1024 && !raised.exchange(true))
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3(bg.nblocks), dim3(kBandLanes), lds, st, src, dst, bg, args...);
+    hipLaunchKernelGGL(kern, dim3(bg.nblocks), dim3((bg.tile_lanes + 63) / 64 * 64), lds, st, src, dst, bg, args...);
 }
 
 template <int K>
@@ -1272,6 +1276,12 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
         // rows of whole 16-byte lanes, at least one full 4 KiB tile wide: LDS band tiles (5-10 % faster than the strip
         // walker on BGR frames: 229 vs 248 us for 5 taps, 206 vs 232 us for 3 taps per 24 x 4K, scripts/dev/bandab.py)
         int band = g.L % 16 == 0 && g.nlanes >= 256 ? (k == 3 ? 8 : 12) : 0;   // 3 taps: 3 blocks of 41 KiB per CU; 5 taps: 2 of 66 KiB
+        if (k == 5) {
+            // 5 taps gain little (2-5 % on 4K / 8K rows) and only when the equal-width tiles fill the block's four waves:
+            // on 1080p BGR rows (2 tiles of 180 lanes) the walker is as fast per launch and 2-4 % faster in a pipeline
+            const int ntx = (g.nlanes + kBandLanes - 1) / kBandLanes;
+            if ((g.nlanes + ntx - 1) / ntx < 224) band = 0;           // mean tile width in lanes
+        }
 #ifdef IPX_DEV
         band = env_int("IPX_BAND_ROWS", band);                        // development: A/B (0 = strip walker)
         if (g.L % 16) band = 0;
