@@ -133,7 +133,7 @@ def main():
     bgr = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=g).to(dev)
 
     STEP_OPS = [  # name, kernels, algorithmic bytes per pixel
-        ("gaussian5_bgr", "sep_pow2_band_kernel<3,5,256>", 6),
+        ("gaussian5_bgr", "sep_pow2_band_kernel<3,5>", 6),
         ("bgr2gray_equalize", "gray_hist_kernel<3>+hist_finish_kernel+lut_kernel", 6),
         ("sobel3_gray", "conv3_kernel<SOBEL,1>", 2),
     ]
@@ -254,7 +254,7 @@ def main():
         if args.ops_table:
             gray = ops.bgr2gray(bgr)
             for name, kern, bpp, fn in [
-                ("gaussian5_bgr_b2b", "sep_pow2_band_kernel<3,5,256>", 6, lambda: ops.gaussian_blur(bgr, 5)),
+                ("gaussian5_bgr_b2b", "sep_pow2_band_kernel<3,5>", 6, lambda: ops.gaussian_blur(bgr, 5)),
                 ("bgr2gray", "gray_kernel<3,false>", 4, lambda: ops.bgr2gray(bgr)),
                 ("sobel3_gray_b2b", "conv3_kernel<SOBEL,1>", 2, lambda: ops.sobel(gray)),
                 ("box3_gray", "conv3_kernel<BOX,1>", 2, lambda: ops.box3(gray)),
