@@ -75,6 +75,9 @@ for k, c in sorted(pmc.items()):
     lines.append(f"| `{k}` | {us:.1f} | {rd:.1f} | {wr:.1f} | {rd + wr:.1f} | " +
                  (f"{amb:.1f} | {(rd + wr) / amb:.3f} | {amb / us * 1e3:.0f} | {amb / us * 1e3 / 8000:.3f} |" if a else "- | - | - | - |"))
     traffic_json[k] = int((rd + wr) * 1e6)
+notes = os.path.join(out, f"{name}_pmc_notes.txt")                # hand-written remarks kept next to the generated table
+if os.path.exists(notes):
+    lines += ["", open(notes).read().rstrip()]
 open(os.path.join(out, f"{name}_pmc.md"), "w").write("\n".join(lines) + "\n")
 json.dump({"gaussian5_bgr": (traffic_json.get("sep_pow2_band_kernel<3, 5>") or traffic_json.get("sep_pow2_kernel<3, 5>") or traffic_json.get("sep_small_kernel<3, 5>")), "batch_per_gpu": B, "per_kernel_bytes": traffic_json,
            "source": f"profiles/{name}_pmc.md", "recorded_at": f"round {int(name[1:3])}" if name[1:3].isdigit() else name}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
