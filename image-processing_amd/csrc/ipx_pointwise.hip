@@ -87,6 +87,59 @@ __global__ __launch_bounds__(kThreads) void lut_kernel(const uint8_t* __restrict
     }
 }
 
+// k tables applied to ONE read of the source: dst[j] = lut[j][src], j < k <= IPX_MAX_MULTI_LUT.  The pixel-wise modes of
+// the reference (server.py:370-388, 459-467) all start from the same gray image; a batch pipeline that wants several of
+// them pays 1 + k bytes per pixel here instead of 2 k.  Tables are per image (device memory, k x 256 bytes per image).
+struct MultiDst { uint8_t* p[IPX_MAX_MULTI_LUT]; };
+
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void lut_multi_kernel(const uint8_t* __restrict__ src, MultiDst dst, int k, PwGeom g,
+                                                             const uint8_t* __restrict__ luts_dev, int64_t lut_img_stride)
+{
+    __shared__ uint32_t s_lut[IPX_MAX_MULTI_LUT * 64];
+    const unsigned img = blockIdx.y;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    bool have_lut = false;
+    for (unsigned u = blockIdx.x; u < g.units_per_img; u += gridDim.x) {
+        const unsigned row = u / g.units_per_row;
+        const int64_t col0 = (int64_t)(u - row * g.units_per_row) * kUnit + (int64_t)threadIdx.x * 16;
+        const uint8_t* sp = simg + (int64_t)row * g.s_row;
+        const int64_t doff = (int64_t)img * g.d_img + (int64_t)row * g.d_row;
+        u32x4 v[kUnroll];
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            const int64_t c = col0 + (int64_t)j * kChunk;
+            if (c + 16 <= g.len) v[j] = ld16x<NT>(sp + c);
+        }
+        if (!have_lut) {                                     // block-uniform; after the first unit's loads are in flight
+            const uint8_t* lp = luts_dev + (int64_t)img * lut_img_stride;
+            for (int i = (int)threadIdx.x; i < 64 * k; i += kThreads) {
+                uint32_t w;
+                __builtin_memcpy(&w, lp + 4 * i, 4);
+                s_lut[i] = w;
+            }
+            __syncthreads();
+            have_lut = true;
+        }
+        for (int t = 0; t < k; ++t) {
+            const uint8_t* sl = reinterpret_cast<const uint8_t*>(s_lut) + 256 * t;
+            uint8_t* dp = dst.p[t] + doff;
+#pragma unroll
+            for (int j = 0; j < kUnroll; ++j) {
+                const int64_t c = col0 + (int64_t)j * kChunk;
+                if (c + 16 <= g.len) {
+                    u32x4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = lut4(sl, v[j][q]);
+                    st16x<NT>(dp + c, o);
+                } else if (c < g.len) {
+                    for (int64_t b = c; b < g.len; ++b) dp[b] = sl[sp[b]];
+                }
+            }
+        }
+    }
+}
+
 // 16 gray (or table[gray]) bytes from a lane's 16 pixels
 template <int C, bool WITH_LUT>
 __device__ __forceinline__ u32x4 gray16(const PxVec<C>& p, const uint8_t* sl)
@@ -287,6 +340,38 @@ int ipx_lut_dev_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h,
     if (lut_stride != 0 && lut_stride < 256) { ipx_clear_error(); return ipx_fail(IPX_ERR_INVALID, "ipx_lut_dev_u8: lut_stride %lld must be 0 or >= 256", (long long)lut_stride); }
     return launch_lut("ipx_lut_dev_u8", stream, src, dst, n, h, w, c, src_row_stride, src_img_stride,
                       dst_row_stride, dst_img_stride, nullptr, lut_dev, lut_stride);
+}
+
+int ipx_lut_multi_u8(void* stream, const uint8_t* src, uint8_t* const* dsts, int k, int n, int h, int w, int c,
+                     int64_t src_row_stride, int64_t src_img_stride, int64_t dst_row_stride, int64_t dst_img_stride,
+                     const uint8_t* luts_dev, int64_t lut_img_stride)
+{
+    const char* fn = "ipx_lut_multi_u8";
+    ipx_clear_error();
+    if (k < 1 || k > IPX_MAX_MULTI_LUT) return ipx_fail(IPX_ERR_INVALID, "%s: k=%d must be in 1..%d", fn, k, IPX_MAX_MULTI_LUT);
+    if (!dsts || !luts_dev) return ipx_fail(IPX_ERR_INVALID, "%s: null %s", fn, dsts ? "tables" : "destination list");
+    if (lut_img_stride != 0 && lut_img_stride < 256 * (int64_t)k)
+        return ipx_fail(IPX_ERR_INVALID, "%s: lut_img_stride %lld must be 0 or >= %d", fn, (long long)lut_img_stride, 256 * k);
+    MultiDst md{};
+    for (int j = 0; j < k; ++j) {
+        if (int rc = ipx_check_image_args(fn, src, dsts[j], n, h, w, c, c, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride)) return rc;
+        for (int i = 0; i < j; ++i)
+            if (dsts[i] == dsts[j]) return ipx_fail(IPX_ERR_INVALID, "%s: destinations %d and %d are the same buffer", fn, i, j);
+        md.p[j] = dsts[j];
+    }
+    PwGeom g = make_geom(h, (int64_t)w * c, 1, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride, kUnit);
+    if (int rc = check_units(fn, g, h, (int64_t)w * c, kUnit)) return rc;
+    g.reverse = 0;
+    const bool nt = ipx_use_nt((uint64_t)(1 + k) * n * h * w * c, kNtLut);
+    for (int i0 = 0; i0 < n; i0 += 65535) {
+        const int nb = n - i0 < 65535 ? n - i0 : 65535;
+        MultiDst d = md;
+        for (int j = 0; j < k; ++j) d.p[j] += (int64_t)i0 * dst_img_stride;
+        hipLaunchKernelGGL(nt ? lut_multi_kernel<true> : lut_multi_kernel<false>, make_grid(g, nb), dim3(kThreads), 0, (hipStream_t)stream,
+                           src + (int64_t)i0 * src_img_stride, d, k, g, luts_dev + (int64_t)i0 * lut_img_stride, lut_img_stride);
+        IPX_LAUNCH_CHECK("lut_multi_kernel");
+    }
+    return IPX_OK;
 }
 
 int ipx_bgr2gray_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int src_channels,

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("IPX_LIB", os.path.join(_HERE, "..", "lib", "libipx.so
 
 IPX_OK, IPX_ERR_INVALID, IPX_ERR_HIP, IPX_ERR_UNSUPPORTED = 0, -1, -2, -3
 MAX_GAUSS_K = 255
+MAX_MULTI_LUT = 8
 NOALLOC_SCRATCH_BYTES = 1536 * 1024
 
 
@@ -33,6 +34,7 @@ SIGNATURES = {
     "ipx_bgr2gray_u8": (_i, _IMG + [_i] + _STR),
     "ipx_lut_u8": (_i, _IMG + [_i] + _STR + [_vp]),
     "ipx_lut_dev_u8": (_i, _IMG + [_i] + _STR + [_vp, _i64]),
+    "ipx_lut_multi_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i] + _STR + [_vp, _i64]),
     "ipx_bgr2gray_lut_u8": (_i, _IMG + [_i] + _STR + [_vp]),
     "ipx_hist_workspace_bytes": (_sz, [_i, _i, _i]),
     "ipx_hist_u8": (_i, [_vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _sz]),

@@ -31,14 +31,19 @@ def gamma(gamma_val: float) -> np.ndarray:
     return np.clip((s * 255.0), 0, 255).astype(np.uint8)
 
 
+def log_curve(c_val: float) -> np.ndarray:
+    """log1p(c * r) of server.py:385-386 on the 256 levels (float32, increasing in the level)."""
+    r = _LEVELS.astype(np.float32) / 255.0
+    return np.log1p(c_val * r)
+
+
 def log(c_val: float, present: np.ndarray) -> np.ndarray:
     """server.py:385-388.  `s.max()` runs over the image, i.e. over the levels that occur in it:
     `present` is a 256-vector (histogram or boolean) marking them."""
     present = np.asarray(present).reshape(256) > 0
     if not present.any():
         raise ValueError("empty image")
-    r = _LEVELS.astype(np.float32) / 255.0
-    s = np.log1p(c_val * r)
+    s = log_curve(c_val)
     with np.errstate(all="ignore"):
         s /= (s[present].max() + 1e-12)
         return (s * 255.0).astype(np.uint8)

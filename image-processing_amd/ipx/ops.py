@@ -131,6 +131,27 @@ def apply_lut_dev(src: torch.Tensor, luts: torch.Tensor) -> torch.Tensor:
     return s.restore(out)
 
 
+def apply_luts_dev(src: torch.Tensor, luts: torch.Tensor) -> list:
+    """k tables applied to ONE read of the source (ipx_lut_multi_u8): luts is (k, 256) shared or (N, k, 256) per image,
+    uint8 on the source's device, k <= 8; returns the k outputs in table order."""
+    import ctypes
+    s = _Img(src)
+    if luts.dtype != torch.uint8 or luts.device != s.t.device or luts.shape[-1] != 256 or luts.ndim not in (2, 3):
+        raise ValueError("luts: uint8 tensor of shape (k, 256) or (N, k, 256) on the source's device expected")
+    luts = luts.contiguous()
+    k = luts.shape[-2]
+    if not 1 <= k <= _lib.MAX_MULTI_LUT:
+        raise ValueError(f"1..{_lib.MAX_MULTI_LUT} tables expected")
+    if luts.ndim == 3 and luts.shape[0] != s.n:
+        raise ValueError("one set of tables per image expected")
+    with torch.cuda.device(s.t.device):
+        outs = [s.like() for _ in range(k)]
+        ptrs = (ctypes.c_void_p * k)(*[o.data_ptr() for o in outs])
+        _lib.call("ipx_lut_multi_u8", _stream(), s.ptr, ctypes.cast(ptrs, ctypes.c_void_p), k, s.n, s.h, s.w, s.c,
+                  s.row, s.img, s.w * s.c, s.w * s.c * s.h, luts.data_ptr(), 0 if luts.ndim == 2 else 256 * k)
+    return [s.restore(o) for o in outs]
+
+
 def bgr2gray_lut(src: torch.Tensor, lut) -> torch.Tensor:
     """Fused cvtColor(BGR2GRAY) + table (one 4 B/px pass instead of 4 + 2)."""
     s = _Img(src)

@@ -13,29 +13,57 @@ FULL_PIPELINE_TABLES = (("negative", luts.negative), ("threshold", lambda: luts.
                         ("piecewise", lambda: luts.piecewise(*luts.piecewise_clamp(70, 10, 180, 245))))
 
 
-def log_transform(ops, gray, c: float = 2.0):
-    """mode=log (server.py:383-388) on a batch: `s.max()` is per image, so each image gets its OWN table, built on the
-    host from that image's device histogram (one small D2H of N x 256 counts) and applied with per-image device
-    tables in one launch."""
+_DEV_CONST = {}
+
+
+def _dev_const(key, device, make):
+    """Small constant tensors (tables, curves) kept on each device: uploading them per call would put a blocking pageable
+    copy into the middle of an otherwise asynchronous pipeline."""
+    k = (key, str(device))
+    if k not in _DEV_CONST:
+        _DEV_CONST[k] = make().to(device)
+    return _DEV_CONST[k]
+
+
+def log_tables_dev(hists, c: float = 2.0):
+    """mode=log tables (server.py:385-388) for a batch, built ON THE DEVICE from the images' histograms (N x 256 counts):
+    `s.max()` is per image and `s` increases with the level, so the maximum is `s` at the highest level present; then the
+    reference's two float32 operations per level, `s / (max + 1e-12)` and `* 255`, and the uint8 truncation -- the same
+    IEEE operations torch performs elementwise (checked against luts.log for every possible highest level in
+    tests/test_gpu_parity.py).  No host round trip: the pipeline stays asynchronous."""
     import torch
-    hists = ops.hist(gray)
-    present = hists.reshape(-1, 256).cpu().numpy()
-    tabs = np.stack([luts.log(c, p) for p in present])
-    if tabs.shape[0] == 1:
-        return ops.apply_lut(gray, tabs[0])
-    return ops.apply_lut_dev(gray, torch.from_numpy(tabs).to(gray.device, non_blocking=True))
+    dev = hists.device
+    s = _dev_const(("log_curve", float(c)), dev, lambda: torch.from_numpy(luts.log_curve(c)))   # float32 (256,), numpy's log1p
+    levels = _dev_const("levels", dev, lambda: torch.arange(256))
+    eps = _dev_const("eps", dev, lambda: torch.tensor(1e-12, dtype=torch.float32))
+    top = ((hists.reshape(-1, 256) > 0) * levels).amax(dim=1)                         # highest level present, per image
+    d = s[top] + eps
+    return ((s[None, :] / d[:, None]) * 255.0).to(torch.uint8)                        # N x 256
+
+
+def log_transform(ops, gray, c: float = 2.0):
+    """mode=log (server.py:383-388) on a batch: each image gets its OWN table (log_tables_dev), applied in one launch."""
+    return ops.apply_lut_dev(gray, log_tables_dev(ops.hist(gray), c))
 
 
 def full_pipeline(ops, bgr) -> dict:
     """BASELINE.json configs[2] "full filter pipeline" on a batch of BGR frames (N x H x W x 3): every pixel-wise mode
     of the reference on the gray image (server.py:360 then :376, :380, :370-372, :385-388, :459-467), histogram
     equalization (:245-246), colour Laplacian sharpening (:263-277) and the 5x5 Gaussian (:428, per channel).
-    Returns the nine output batches by mode name (plus 'gray')."""
-    gray, eq = ops.bgr2gray_equalize(bgr)                      # one pass over the colour source for gray8 + histogram_eq
+    Returns the nine output batches by mode name (plus 'gray').
+    The five table modes read the gray batch ONCE (ipx_lut_multi_u8: 1 + 5 bytes per pixel instead of 10); the log table
+    is per image (`s.max()`, server.py:387), built on the device from the histogram the gray conversion already produced."""
+    import torch
+    gray, eq, hists, _ = ops.bgr2gray_equalize(bgr, return_aux=True)   # one pass over the colour source: gray8 + histogram_eq
     out = {"gray": gray, "histogram_eq": eq}
-    for name, make in FULL_PIPELINE_TABLES:
-        out[name] = ops.apply_lut(gray, make())
-    out["log"] = log_transform(ops, gray, 2.0)
+    n = hists.reshape(-1, 256).shape[0]
+    shared = _dev_const("full_pipeline_tables", gray.device,
+                        lambda: torch.from_numpy(np.stack([make() for _, make in FULL_PIPELINE_TABLES]).astype(np.uint8)))
+    tabs = torch.cat([shared[None].expand(n, -1, -1), log_tables_dev(hists, 2.0)[:, None, :]], dim=1).contiguous()   # N x 5 x 256
+    res = ops.apply_luts_dev(gray, tabs)
+    for (name, _), r in zip(FULL_PIPELINE_TABLES, res):
+        out[name] = r
+    out["log"] = res[len(FULL_PIPELINE_TABLES)]
     out["sharpening"] = ops.laplacian_sharpen(bgr)
     out["gaussian5"] = ops.gaussian_blur(bgr, 5)
     return out

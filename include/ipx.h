@@ -77,6 +77,18 @@ int ipx_lut_dev_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h,
                    int64_t dst_row_stride, int64_t dst_img_stride,
                    const uint8_t* lut_dev, int64_t lut_stride);
 
+/* k tables applied to ONE read of the source: dsts[j] = lut_j[src] for j < k <= IPX_MAX_MULTI_LUT.  The pixel-wise modes of
+ * the reference all start from the same gray image (negative server.py:376, threshold :380, gamma :370-372, log :385-388,
+ * piecewise :459-467); a batch pipeline that wants several of them (BASELINE.json configs[2]) pays 1 + k bytes per pixel
+ * instead of 2 k.  `dsts` is a HOST array of k distinct device pointers (all with the dst strides; none may alias src);
+ * image i, output j uses the 256-byte table at luts_dev + i*lut_img_stride + 256*j (DEVICE memory; lut_img_stride 0 = one
+ * shared set, else >= 256 k). */
+#define IPX_MAX_MULTI_LUT 8
+int ipx_lut_multi_u8(void* stream, const uint8_t* src, uint8_t* const* dsts, int k, int n, int h, int w, int c,
+                     int64_t src_row_stride, int64_t src_img_stride,
+                     int64_t dst_row_stride, int64_t dst_img_stride,
+                     const uint8_t* luts_dev, int64_t lut_img_stride);
+
 /* Fused cvtColor(BGR2GRAY) + table: dst = lut[gray(src)] (server.py:360 followed by any of :362-388,
  * :443-467 in one pass, 4 B/px instead of 4 + 2). */
 int ipx_bgr2gray_lut_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int src_channels,

@@ -130,6 +130,63 @@ def test_equalize_lut_from_large_histograms(dev):
 CONV = [("laplacian_sharpen", O.laplacian_sharpen_u8), ("box3", O.box3_u8), ("sobel", O.sobel_u8)]
 
 
+def test_log_tables_built_on_the_device(dev):
+    """pipelines.log_tables_dev == luts.log (the reference's numpy expressions) for every possible highest level present,
+    several c; all-zero images included (level 0 only)."""
+    import ipx.pipelines as P
+    for c in (0.5, 1.0, 2.0, 7.3):
+        hists = np.zeros((256, 256), np.int32)
+        for top in range(256):
+            hists[top, top] = 5
+            if top > 3:
+                hists[top, top // 2] = 1
+        got = host(P.log_tables_dev(dev_t(hists, dev), c))
+        for top in range(256):
+            want = luts.log(c, hists[top])
+            lv = np.nonzero(hists[top])[0]                        # only levels that occur are ever looked up
+            np.testing.assert_array_equal(got[top][:top + 1], want[:top + 1], err_msg=f"c={c} top={top}")
+            assert (got[top][lv] == want[lv]).all()
+
+
+def test_multi_table_pass(dev):
+    """ipx_lut_multi_u8: k tables on one read of the source == k single table passes; shared and per-image tables, every k,
+    ragged rows, colour, a strided batch with an unaligned base; argument errors."""
+    import ipx._lib as L
+    rng = np.random.default_rng(66)
+    for shape in ((1, 1, 1, 1), (2, 7, 33, 1), (3, 40, 1111, 1), (2, 19, 300, 3), (1, 5, 16400, 1)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        t = dev_t(img, dev)
+        for k in (1, 2, 5, 8):
+            shared = rng.integers(0, 256, (k, 256), dtype=np.uint8)
+            got = ops.apply_luts_dev(t, dev_t(shared, dev))
+            assert len(got) == k
+            for j in range(k):
+                np.testing.assert_array_equal(host(got[j]), shared[j][img], err_msg=f"{shape} k={k} j={j}")
+            per = rng.integers(0, 256, (shape[0], k, 256), dtype=np.uint8)
+            got = ops.apply_luts_dev(t, dev_t(per, dev))
+            for j in range(k):
+                for i in range(shape[0]):
+                    np.testing.assert_array_equal(host(got[j])[i], per[i, j][img[i]], err_msg=f"{shape} k={k} img={i} j={j}")
+    big = rng.integers(0, 256, (3, 50, 1300), dtype=np.uint8)
+    view = dev_t(big, dev)[:, 3:47, 5:5 + 1111].unsqueeze(-1)
+    tabs = rng.integers(0, 256, (3, 4, 256), dtype=np.uint8)
+    got = ops.apply_luts_dev(view, dev_t(tabs, dev))
+    for j in range(4):
+        for i in range(3):
+            np.testing.assert_array_equal(host(got[j])[i, :, :, 0], tabs[i, j][big[i, 3:47, 5:1116]])
+    t = dev_t(rng.integers(0, 256, (2, 8, 8, 1), dtype=np.uint8), dev)
+    with pytest.raises(ValueError):
+        ops.apply_luts_dev(t, dev_t(np.zeros((9, 256), np.uint8), dev))
+    with pytest.raises(ValueError):
+        ops.apply_luts_dev(t, dev_t(np.zeros((3, 2, 256), np.uint8), dev))       # 3 table sets for 2 images
+    import ctypes
+    tab = dev_t(np.zeros((2, 256), np.uint8), dev)
+    out = torch.empty_like(t)
+    ptrs = (ctypes.c_void_p * 2)(out.data_ptr(), out.data_ptr())                 # the same destination twice
+    with pytest.raises(L.IpxError):
+        L.call("ipx_lut_multi_u8", None, t.data_ptr(), ctypes.cast(ptrs, ctypes.c_void_p), 2, 2, 8, 8, 1, 8, 64, 8, 64, tab.data_ptr(), 0)
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("cn", [1, 2, 3, 4])
 @pytest.mark.parametrize("name,ref", CONV)
