@@ -486,8 +486,15 @@ int ipx_bgr2gray_equalize_u8(void* stream, const uint8_t* src, uint8_t* gray, ui
     }
     if (int rc = ipx_check_image_args(fn, src, gray, n, h, w, src_channels, 1, src_row_stride, src_img_stride,
                                       gray_row_stride, gray_img_stride)) return rc;
-    if (int rc = ipx_check_image_args(fn, gray, dst, n, h, w, 1, 1, gray_row_stride, gray_img_stride,
-                                      dst_row_stride, dst_img_stride)) return rc;
+    // dst == NULL: gray image, histograms and tables only (the caller applies the tables itself, e.g. together with
+    // others in ipx_lut_multi_u8); at least one of hist_out_dev / lut_out_dev must then take the result
+    if (dst) {
+        if (int rc = ipx_check_image_args(fn, gray, dst, n, h, w, 1, 1, gray_row_stride, gray_img_stride,
+                                          dst_row_stride, dst_img_stride)) return rc;
+    } else if (!hist_out_dev && !lut_out_dev) {
+        ipx_clear_error();
+        return ipx_fail(IPX_ERR_INVALID, "%s: dst is null and neither hist_out_dev nor lut_out_dev is given", fn);
+    }
     if (int rc = check_hist_args(fn, gray, n, h, w, gray_row_stride, gray_img_stride)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const size_t need = workspace_layout(n, h, w, nullptr, nullptr);
@@ -521,7 +528,7 @@ int ipx_bgr2gray_equalize_u8(void* stream, const uint8_t* src, uint8_t* gray, ui
                            (const uint32_t*)nullptr, hist_out_dev, lut);
         if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "%s: launch of hist_finish_kernel failed", fn);
     }
-    if (rc == IPX_OK)
+    if (rc == IPX_OK && dst)
         rc = ipx_lut_dev_reversed(stream, gray, dst, n, h, w, gray_row_stride, gray_img_stride, dst_row_stride, dst_img_stride, lut, 256);
     if (own) {
         hipError_t e = hipFreeAsync(own, st);

@@ -257,6 +257,24 @@ def bgr2gray_equalize(src: torch.Tensor, return_aux: bool = False):
     return (gray, out, hst, lut) if return_aux else (gray, out)
 
 
+def bgr2gray_hist(src: torch.Tensor):
+    """cvtColor(BGR2GRAY) + per-image histogram + equalizeHist TABLE in one pass over the colour source, without applying
+    the table (ipx_bgr2gray_equalize_u8 with dst = NULL): returns (gray, hist (N x 256 int32), lut (N x 256 uint8))."""
+    s = _Img(src)
+    if s.c not in (3, 4):
+        raise ValueError("bgr2gray_hist needs 3 (BGR) or 4 (BGRA) channels")
+    with torch.cuda.device(s.t.device):
+        gray = s.like(1)
+        ws = torch.empty((_lib.load().ipx_hist_workspace_bytes(s.n, s.h, s.w),), dtype=torch.uint8, device=s.t.device)
+        hst = torch.empty((s.n, 256), dtype=torch.int32, device=s.t.device)
+        lut = torch.empty((s.n, 256), dtype=torch.uint8, device=s.t.device)
+        _lib.call("ipx_bgr2gray_equalize_u8", _stream(), s.ptr, gray.data_ptr(), None, s.n, s.h, s.w, s.c,
+                  s.row, s.img, s.w, s.w * s.h, s.w, s.w * s.h, hst.data_ptr(), lut.data_ptr(), ws.data_ptr(), ws.numel())
+    if src.ndim == 3:
+        gray = gray[0, :, :, 0]
+    return gray, hst, lut
+
+
 # ---- convolutions --------------------------------------------------------------------------------
 def _conv3(name: str, src: torch.Tensor, top: Optional[torch.Tensor], bottom: Optional[torch.Tensor]) -> torch.Tensor:
     s = _Img(src)

@@ -51,19 +51,24 @@ def full_pipeline(ops, bgr) -> dict:
     of the reference on the gray image (server.py:360 then :376, :380, :370-372, :385-388, :459-467), histogram
     equalization (:245-246), colour Laplacian sharpening (:263-277) and the 5x5 Gaussian (:428, per channel).
     Returns the nine output batches by mode name (plus 'gray').
-    The five table modes read the gray batch ONCE (ipx_lut_multi_u8: 1 + 5 bytes per pixel instead of 10); the log table
-    is per image (`s.max()`, server.py:387), built on the device from the histogram the gray conversion already produced."""
+    The six table modes (equalizeHist's table pass among them) read the gray batch ONCE (ipx_lut_multi_u8: 1 + 6 bytes per
+    pixel instead of 12); the log table is per image (`s.max()`, server.py:387), built on the device from the histogram the
+    gray conversion already produced."""
     import torch
-    gray, eq, hists, _ = ops.bgr2gray_equalize(bgr, return_aux=True)   # one pass over the colour source: gray8 + histogram_eq
-    out = {"gray": gray, "histogram_eq": eq}
+    gray, hists, eq_lut = ops.bgr2gray_hist(bgr)                # one pass over the colour source: gray8, histograms, equalize tables
+    out = {"gray": gray}
     n = hists.reshape(-1, 256).shape[0]
     shared = _dev_const("full_pipeline_tables", gray.device,
                         lambda: torch.from_numpy(np.stack([make() for _, make in FULL_PIPELINE_TABLES]).astype(np.uint8)))
-    tabs = torch.cat([shared[None].expand(n, -1, -1), log_tables_dev(hists, 2.0)[:, None, :]], dim=1).contiguous()   # N x 5 x 256
-    res = ops.apply_luts_dev(gray, tabs)
+    tabs = torch.cat([shared[None].expand(n, -1, -1), log_tables_dev(hists, 2.0)[:, None, :], eq_lut.reshape(n, 1, 256)],
+                     dim=1).contiguous()                            # N x 6 x 256
+    res = ops.apply_luts_dev(gray if gray.ndim == 4 else gray[None, :, :, None], tabs)
+    if gray.ndim != 4:
+        res = [r[0, :, :, 0] for r in res]
     for (name, _), r in zip(FULL_PIPELINE_TABLES, res):
         out[name] = r
     out["log"] = res[len(FULL_PIPELINE_TABLES)]
+    out["histogram_eq"] = res[len(FULL_PIPELINE_TABLES) + 1]
     out["sharpening"] = ops.laplacian_sharpen(bgr)
     out["gaussian5"] = ops.gaussian_blur(bgr, 5)
     return out

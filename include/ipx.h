@@ -141,7 +141,9 @@ int ipx_equalize_hist_noalloc_u8(void* stream, const uint8_t* src, uint8_t* dst,
 /* Fused server.py:245-246 for colour input: gray = cv2.cvtColor(img, BGR2GRAY) (kept: `gray` is an output, n x h x w)
  * and dst = cv2.equalizeHist(gray).  The histogram is taken while the gray image is written, so the source is read
  * once (3 + 1 + 1 + 1 bytes per pixel instead of 3 + 1 and 1 + 1 + 1).  dst may alias gray (in-place table pass).
- * hist_out_dev / lut_out_dev / workspace as in ipx_equalize_hist_u8. */
+ * hist_out_dev / lut_out_dev / workspace as in ipx_equalize_hist_u8.  dst may be NULL: the table pass is then skipped (gray,
+ * histograms and tables only; hist_out_dev or lut_out_dev must be given) for callers that apply the table themselves,
+ * e.g. with others in one ipx_lut_multi_u8 pass. */
 int ipx_bgr2gray_equalize_u8(void* stream, const uint8_t* src, uint8_t* gray, uint8_t* dst, int n, int h, int w,
                              int src_channels, int64_t src_row_stride, int64_t src_img_stride,
                              int64_t gray_row_stride, int64_t gray_img_stride,

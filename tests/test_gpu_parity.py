@@ -148,6 +148,25 @@ def test_log_tables_built_on_the_device(dev):
             assert (got[top][lv] == want[lv]).all()
 
 
+def test_bgr2gray_hist_without_table_pass(dev):
+    """ipx_bgr2gray_equalize_u8 with dst = NULL: gray image, histograms and equalize tables only (the caller applies the tables,
+    e.g. in ipx_lut_multi_u8); rejected when no output would take the result."""
+    import ipx._lib as L
+    rng = np.random.default_rng(88)
+    for shape in ((1, 5, 7, 3), (3, 40, 333, 3), (2, 64, 1100, 4)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        gray, hst, lut = ops.bgr2gray_hist(dev_t(img, dev))
+        for i in range(shape[0]):
+            want_gray = O.bgr2gray_u8(img[i])
+            np.testing.assert_array_equal(host(gray)[i, :, :, 0], want_gray)
+            np.testing.assert_array_equal(host(hst)[i], np.bincount(want_gray.ravel(), minlength=256))
+            np.testing.assert_array_equal(host(lut)[i], O.equalize_lut_from_hist(np.bincount(want_gray.ravel(), minlength=256)))
+    t = dev_t(rng.integers(0, 256, (1, 8, 8, 3), dtype=np.uint8), dev)
+    g = torch.empty((1, 8, 8, 1), dtype=torch.uint8, device=dev)
+    with pytest.raises(L.IpxError):
+        L.call("ipx_bgr2gray_equalize_u8", None, t.data_ptr(), g.data_ptr(), None, 1, 8, 8, 3, 24, 192, 8, 64, 8, 64, None, None, None, 0)
+
+
 def test_multi_table_pass(dev):
     """ipx_lut_multi_u8: k tables on one read of the source == k single table passes; shared and per-image tables, every k,
     ragged rows, colour, a strided batch with an unaligned base; argument errors."""
