@@ -1135,9 +1135,14 @@ template <auto kern, class... Args>
 void launch_band(hipStream_t st, const BandGeom& bg, int r, const uint8_t* src, uint8_t* dst, Args... args)
 {
     const size_t lds = (size_t)(bg.band_rows + 2 * r) * bg.pitch;
-    static std::atomic<bool> raised{false};                       // per kernel (template instance): tiles above 64 KiB need the limit raised once
-    if (lds > 64 * 1024 && !raised.exchange(true))
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 64 * 1024) {                                        // tiles above 64 KiB: raise the kernel's limit, once per kernel
+        static std::atomic<uint64_t> raised{0};                   // (template instance) and DEVICE (one process may drive several GPUs)
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(raised.fetch_or(bit) & bit))
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     hipLaunchKernelGGL(kern, dim3(bg.nblocks), dim3((bg.tile_lanes + 63) / 64 * 64), lds, st, src, dst, bg, args...);
 }
 
