@@ -12,9 +12,6 @@
 #include <stdlib.h>
 #include <atomic>
 
-int ipx_lut_dev_reversed(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
-                         int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* lut_dev, int64_t lut_stride);
-
 namespace {
 
 constexpr int kThreads = 512;                  // 8 waves share one 32 KiB LDS histogram: 4 blocks = 32 waves per CU
@@ -348,7 +345,7 @@ int equalize_with_workspace(hipStream_t st, const uint8_t* src, uint8_t* dst, in
                        (const uint32_t*)nullptr, hist_out_dev, lut);
     IPX_LAUNCH_CHECK("hist_finish_kernel");
     // the table pass walks the batch back to front: what the histogram pass read last is still in the Infinity Cache
-    return ipx_lut_dev_reversed((void*)st, src, dst, n, h, w, s_row, s_img, d_row, d_img, lut, 256);
+    return ipx_lut_dev_u8((void*)st, src, dst, n, h, w, 1, s_row, s_img, d_row, d_img, lut, 256);
 }
 
 // ---- scratch of the no-allocation entry point ---------------------------------------------------------------------
@@ -529,7 +526,7 @@ int ipx_bgr2gray_equalize_u8(void* stream, const uint8_t* src, uint8_t* gray, ui
         if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "%s: launch of hist_finish_kernel failed", fn);
     }
     if (rc == IPX_OK && dst)
-        rc = ipx_lut_dev_reversed(stream, gray, dst, n, h, w, gray_row_stride, gray_img_stride, dst_row_stride, dst_img_stride, lut, 256);
+        rc = ipx_lut_dev_u8(stream, gray, dst, n, h, w, 1, gray_row_stride, gray_img_stride, dst_row_stride, dst_img_stride, lut, 256);
     if (own) {
         hipError_t e = hipFreeAsync(own, st);
         if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));

@@ -21,7 +21,6 @@ struct PwGeom {
     int64_t s_row, s_img, d_row, d_img;
     unsigned units_per_row;  // ceil(len / kUnit)
     unsigned units_per_img;  // rows * units_per_row
-    int reverse;             // walk images and units from the END of the batch backwards (same result; see launch_lut)
 };
 
 __device__ __forceinline__ uint32_t lut4(const uint8_t* sl, uint32_t x)
@@ -50,14 +49,13 @@ __global__ __launch_bounds__(kThreads) void lut_kernel(const uint8_t* __restrict
                                                        int64_t lut_stride)
 {
     __shared__ uint32_t s_lut[64];
-    const unsigned img = g.reverse ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+    const unsigned img = blockIdx.y;
     const uint8_t* sl = reinterpret_cast<const uint8_t*>(s_lut);
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     bool have_lut = false;
 
-    for (unsigned ub = blockIdx.x; ub < g.units_per_img; ub += gridDim.x) {
-        const unsigned u = g.reverse ? g.units_per_img - 1 - ub : ub;
+    for (unsigned u = blockIdx.x; u < g.units_per_img; u += gridDim.x) {
         const unsigned row = u / g.units_per_row;
         const int64_t col0 = (int64_t)(u - row * g.units_per_row) * kUnit + (int64_t)threadIdx.x * 16;
         const uint8_t* sp = simg + (int64_t)row * g.s_row;
@@ -223,7 +221,6 @@ PwGeom make_geom(int h, int64_t len_in_row, int in_bpe, int64_t s_row, int64_t s
     PwGeom g;
     g.rows = h; g.len = len_in_row;
     g.s_row = s_row; g.s_img = s_img; g.d_row = d_row; g.d_img = d_img;
-    g.reverse = 0;
     if (s_row == len_in_row * in_bpe && d_row == len_in_row) {   // contiguous image: one long row
         g.rows = 1; g.len = len_in_row * (int64_t)h;
     }
@@ -249,11 +246,11 @@ int check_units(const char* fn, const PwGeom& g, int h, int64_t len, int unit)
     return IPX_OK;
 }
 
-// reverse: the blocks walk the batch from its end to its start.  Used for the table pass of equalizeHist: the histogram
-// pass before it read (or wrote) the image front to back, so its END is what the 256 MiB Infinity Cache still holds.
+// (Tried and removed, round 2: walking the batch from its END for the table pass of equalizeHist, so that its first reads hit
+// what the histogram pass left in the 256 MiB Infinity Cache -- no measurable difference.)
 int launch_lut(const char* fn, void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
                int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
-               const uint8_t* lut_host, const uint8_t* lut_dev, int64_t lut_stride, bool reverse = false)
+               const uint8_t* lut_host, const uint8_t* lut_dev, int64_t lut_stride)
 {
     if (int rc = ipx_check_image_args(fn, src, dst, n, h, w, c, c, s_row, s_img, d_row, d_img)) return rc;
     PwGeom g = make_geom(h, (int64_t)w * c, 1, s_row, s_img, d_row, d_img, kUnit);
@@ -262,13 +259,9 @@ int launch_lut(const char* fn, void* stream, const uint8_t* src, uint8_t* dst, i
     LutArg la{};
     if (lut_host) __builtin_memcpy(la.w, lut_host, 256);
     const bool nt = ipx_use_nt(2ull * (uint64_t)n * h * w * c, kNtLut);
-#ifdef IPX_DEV
-    if (getenv("IPX_NO_REVERSE")) reverse = false;                 // A/B switch of development builds
-#endif
-    g.reverse = reverse ? 1 : 0;
     const int nchunks = (n + 65534) / 65535;
     for (int ci = 0; ci < nchunks; ++ci) {
-        const int i0 = (reverse ? nchunks - 1 - ci : ci) * 65535;
+        const int i0 = ci * 65535;
         const int nb = n - i0 < 65535 ? n - i0 : 65535;
         const uint8_t* s = src + (int64_t)i0 * s_img;
         uint8_t* d = dst + (int64_t)i0 * d_img;
@@ -314,13 +307,6 @@ int launch_gray(const char* fn, void* stream, const uint8_t* src, uint8_t* dst, 
 
 }  // namespace
 
-// Table pass of the equalizeHist entry points (ipx_hist.hip): per-image device tables, batch walked back to front.
-int ipx_lut_dev_reversed(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
-                         int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* lut_dev, int64_t lut_stride)
-{
-    return launch_lut("ipx_lut_dev_u8", stream, src, dst, n, h, w, 1, s_row, s_img, d_row, d_img, nullptr, lut_dev, lut_stride, true);
-}
-
 extern "C" {
 
 int ipx_lut_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
@@ -361,7 +347,6 @@ int ipx_lut_multi_u8(void* stream, const uint8_t* src, uint8_t* const* dsts, int
     }
     PwGeom g = make_geom(h, (int64_t)w * c, 1, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride, kUnit);
     if (int rc = check_units(fn, g, h, (int64_t)w * c, kUnit)) return rc;
-    g.reverse = 0;
     const bool nt = ipx_use_nt((uint64_t)(1 + k) * n * h * w * c, kNtLut);
     for (int i0 = 0; i0 < n; i0 += 65535) {
         const int nb = n - i0 < 65535 ? n - i0 : 65535;
