@@ -27,7 +27,8 @@ a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 dev = torch.device("cuda:0")
 
-EDGE_W = [1, 2, 5, 15, 16, 17, 31, 33, 63, 64, 65, 127, 128, 129, 341, 342, 343, 1023, 1024, 1025, 1365, 2047, 2049]
+EDGE_W = [1, 2, 5, 15, 16, 17, 31, 33, 63, 64, 65, 127, 128, 129, 341, 342, 343, 1023, 1024, 1025, 1365, 2047, 2049,
+          1376, 2064, 2752, 4096, 4112, 1440]            # rows of whole 16-byte lanes >= 4 KiB at 1-4 channels: the LDS band-tile kernels
 
 
 def rand_shape(max_px=400_000):
