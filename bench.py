@@ -266,12 +266,13 @@ def main():
                 ("lut_gray", "lut_kernel<true>", 2, lambda: ops.apply_lut(gray, list(range(255, -1, -1)))),
                 ("lut_bgr", "lut_kernel<true>", 6, lambda: ops.apply_lut(bgr, list(range(255, -1, -1)))),
                 # SURVEY.md section 8(f) kernels, 2 B/px algorithmic each (gray in, gray out)
-                ("lee_w3", "lee_kernel", 2, lambda: ops.lee_filter(gray, 3)),
-                ("lee_w5", "lee_kernel", 2, lambda: ops.lee_filter(gray, 5)),
+                ("lee_w3", "lee_small_kernel<3>", 2, lambda: ops.lee_filter(gray, 3)),
+                ("lee_w5", "lee_small_kernel<5>", 2, lambda: ops.lee_filter(gray, 5)),
+                ("lee_w7", "lee_small_kernel<7>", 2, lambda: ops.lee_filter(gray, 7)),
                 ("lee_w31", "lee_kernel", 2, lambda: ops.lee_filter(gray, 31)),
-                ("erode_3", "morph_kernel", 2, lambda: ops.erode(gray, ops.ellipse_se(3))),
-                ("dilate_5", "morph_kernel", 2, lambda: ops.dilate(gray, ops.ellipse_se(5))),
-                ("median_3", "median_small_kernel<3>", 2, lambda: ops.median_blur(gray, 3)),
+                ("erode_3", "morph_small_kernel<false,1>", 2, lambda: ops.erode(gray, ops.ellipse_se(3))),
+                ("dilate_5", "morph_small_kernel<true,2>", 2, lambda: ops.dilate(gray, ops.ellipse_se(5))),
+                ("median_3", "median3_kernel", 2, lambda: ops.median_blur(gray, 3)),
                 ("median_5", "median_small_kernel<5>", 2, lambda: ops.median_blur(gray, 5)),
                 ("median_31", "median_hist_kernel", 2, lambda: ops.median_blur(gray, 31)),
             ]:

@@ -169,15 +169,15 @@ __global__ __launch_bounds__(kTileW * kTileH) void lee_kernel(const uint8_t* __r
 }
 
 
-// ---- windows of 3 x 3 and 5 x 5: a thread walks down two adjacent image columns ----------------------------------------
-// The general kernel above spends its time on LDS index tables and on four IEEE divisions per pixel.  For K = 3 and 5:
+// ---- windows of 3 x 3, 5 x 5 and 7 x 7: a thread walks down two adjacent image columns ----------------------------------------
+// The general kernel above spends its time on LDS index tables and on four IEEE divisions per pixel.  For K = 3, 5 and 7:
 //   * a lane owns columns x, x + 1 and walks a segment of rows; per row ONE unaligned 4- or 8-byte load gives it bytes
 //     x-k .. x+1+k; the two K x K windows live in registers as PAIRS of floats (window value i of the left and of the
 //     right pixel side by side), ring of K rows, loop unrolled by K: static indices.  All per-pixel arithmetic is then
 //     two-wide (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), every operation separately rounded as before;
 //   * the window sum S is an integer <= 255 n, so mean = fl(S / n) and q = fl(fl(mean^2) / fl(mean + 1e-12)) are
 //     functions of S alone: a (mean, q) table over all S is built per block in LDS with the very same operations
-//     (2 divisions per ENTRY instead of per pixel);
+//     (2 divisions per ENTRY instead of per pixel); K = 7 computes both per pixel instead (its table would not fit);
 //   * the squared deviations are summed in numpy's pairwise order for n < 128 (8 interleaved accumulators over
 //     floor(n / 8) rounds, a balanced tree, the remainder serially), all indices static;
 //   * the two divisions per pixel that remain are sum / n (three operations, div_by_const) and var / (var + q) (the
@@ -192,16 +192,19 @@ template <int K>
 __global__ __launch_bounds__(256) void lee_small_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, LeeSmallGeom g)
 {
     constexpr int k = K / 2, n = K * K, NT = 255 * n + 1, LB = K <= 3 ? 4 : 8;   // LB: bytes per row load (>= K + 1)
+    constexpr bool TABLE = K <= 5;                         // K = 7: the table would take 100 KB of LDS; mean and q are computed
     extern __shared__ float s_tab[];                       // mean[S] = s_tab[S], q[S] = s_tab[NT + S]
     const float fn = (float)n, cn = rn_div(1.0f, fn);
-    for (int i = (int)threadIdx.x; i < NT; i += 256) {
-        const float m = rn_div((float)i, fn);
-        s_tab[i] = m;
-        // S = 0 (an all-zero window: var = 0, mean = 0) would give q = 0 and 0 / 0 below; any positive q there gives the
-        // reference's result (k_lee = 0, out = mean)
-        s_tab[NT + i] = i ? rn_div(rn_mul(m, m), rn_add(m, 1e-12f)) : 1.0f;
+    if (TABLE) {
+        for (int i = (int)threadIdx.x; i < NT; i += 256) {
+            const float m = rn_div((float)i, fn);
+            s_tab[i] = m;
+            // S = 0 (an all-zero window: var = 0, mean = 0) would give q = 0 and 0 / 0 below; any positive q there gives the
+            // reference's result (k_lee = 0, out = mean)
+            s_tab[NT + i] = i ? rn_div(rn_mul(m, m), rn_add(m, 1e-12f)) : 1.0f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const unsigned blk = blockIdx.x;
     const unsigned sub = blk % (unsigned)g.blocks_per_seg, rest = blk / (unsigned)g.blocks_per_seg;
     const unsigned seg = rest % (unsigned)g.nsegs, img = rest / (unsigned)g.nsegs;
@@ -284,8 +287,17 @@ __global__ __launch_bounds__(256) void lee_small_kernel(const uint8_t* __restric
                     f2 S = rs[0];
 #pragma unroll
                     for (int r = 1; r < K; ++r) S = S + rs[r];
-                    const int i0 = (int)S.x, i1 = (int)S.y;
-                    const f2 mean = f2{s_tab[i0], s_tab[i1]}, q = f2{s_tab[NT + i0], s_tab[NT + i1]};
+                    f2 mean, q;
+                    if (TABLE) {
+                        const int i0 = (int)S.x, i1 = (int)S.y;
+                        mean = f2{s_tab[i0], s_tab[i1]};
+                        q = f2{s_tab[NT + i0], s_tab[NT + i1]};
+                    } else {                               // the same values by the same roundings: S / n in three operations,
+                        mean = div_by_const(S, fn, cn);    // fl(mean^2) / fl(mean + 1e-12) with operands >= 1 / n (S = 0: q := 1)
+                        const f2 e12 = f2{1e-12f, 1e-12f};
+                        const f2 qq = div_safe_range(mean * mean, mean + e12);
+                        q = f2{S.x > 0.f ? qq.x : 1.0f, S.y > 0.f ? qq.y : 1.0f};
+                    }
                     auto sq = [&](int i) {                 // window value i in row-major order, both pixels
                         const f2 dv = P[(slot + 1 + i / K) % K][i % K] - mean;
                         return dv * dv;
@@ -335,7 +347,7 @@ extern "C" int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst,
     if (window_size < 1 || window_size / 2 > kMaxK)
         return ipx_fail(IPX_ERR_INVALID, "%s: window_size=%d must be in 1..%d", fn, window_size, 2 * kMaxK + 1);
     const int kk = window_size / 2;                        // server.py:717
-    if ((kk == 1 || kk == 2) && w >= 64) {                 // 3 x 3 and 5 x 5: the column walker
+    if (kk >= 1 && kk <= 3 && w >= 64) {                   // 3 x 3, 5 x 5, 7 x 7: the column walker
         LeeSmallGeom sg;
         sg.h = h; sg.w = w;
         sg.s_row = src_row_stride; sg.s_img = src_img_stride; sg.d_row = dst_row_stride; sg.d_img = dst_img_stride;
@@ -349,9 +361,10 @@ extern "C" int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst,
         sg.nsegs = (h + sg.seg_rows - 1) / sg.seg_rows;
         const uint64_t nb = (uint64_t)n * sg.nsegs * sg.blocks_per_seg;
         if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many blocks", fn);
-        const size_t lds = (size_t)(255 * (2 * kk + 1) * (2 * kk + 1) + 1) * 2 * sizeof(float);
+        const size_t lds = kk <= 2 ? (size_t)(255 * (2 * kk + 1) * (2 * kk + 1) + 1) * 2 * sizeof(float) : 0;
         if (kk == 1) hipLaunchKernelGGL(lee_small_kernel<3>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
-        else hipLaunchKernelGGL(lee_small_kernel<5>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
+        else if (kk == 2) hipLaunchKernelGGL(lee_small_kernel<5>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
+        else hipLaunchKernelGGL(lee_small_kernel<7>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
         IPX_LAUNCH_CHECK("lee_small_kernel");
         return IPX_OK;
     }
