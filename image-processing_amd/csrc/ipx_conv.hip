@@ -451,6 +451,49 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
 // pass on row pairs), which is bound by vector issue, not by memory (SQ_WAIT_INST_ANY 59 %, profiles/r02_notes.md).
 struct Pow2Taps { uint32_t kx1, kx2, ky1, ky2, rnd, sh; };       // inner taps (K = 3: k1 = centre, k2 unused), rounding, shift
 
+// Row pass and column pass of the packed filter, shared by the strip walker and the band-tile kernel.
+template <int C, int K>
+__device__ __forceinline__ void pow2_rowpass(us2 (&h)[8], const Win<C, K / 2>& W, unsigned short kx1, unsigned short kx2)
+{
+    constexpr int R = K / 2;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int p = slot_p(s);
+        if (K == 3) {
+            h[s] = (fld<C, R>(W, p - C) + fld<C, R>(W, p + C)) + fld<C, R>(W, p) * kx1;
+        } else {
+            const us2 o = fld<C, R>(W, p - 2 * C) + fld<C, R>(W, p + 2 * C);
+            const us2 i = fld<C, R>(W, p - C) + fld<C, R>(W, p + C);
+            h[s] = (o + i * kx1) + fld<C, R>(W, p) * kx2;
+        }
+    }
+}
+
+// hb = ring of the last K row-pass results, `slot` the newest (source row y + R of output row y): the 16 output bytes
+template <int K>
+__device__ __forceinline__ u32x4 pow2_colpass(const us2 (&hb)[K][8], int slot, unsigned short ky1, unsigned short ky2, us2 rnd, us2 sh)
+{
+    us2 o[8];
+    // (slot is a compile-time value at every call site -- the callers' loops are unrolled by K -- and so are the ring indices)
+    const int s1 = (slot + 1) % K, s2 = (slot + 2) % K, s3 = (slot + 3) % K, s4 = (slot + 4) % K;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {                                // source rows y - R .. y + R = ring slots (slot + 1 + i) % K
+        us2 v;
+        if (K == 3) {
+            v = (hb[s1][s] + hb[slot][s]) + (hb[s2][s] * ky1 + rnd);
+        } else {
+            const us2 oo = hb[s1][s] + hb[slot][s];
+            const us2 ii = hb[s2][s] + hb[s4][s];
+            v = (oo + ii * ky1) + (hb[s3][s] * ky2 + rnd);
+        }
+        o[s] = v >> sh;
+    }
+    u32x4 ov;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ov[k] = pack_fields(o[2 * k], o[2 * k + 1]);
+    return ov;
+}
+
 template <int C, int K>
 __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void sep_pow2_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                        ConvGeom g, Pow2Taps t)
@@ -476,17 +519,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void sep_pow2_kernel(const 
     us2 hb[K][8];                                                // ring: row-pass results of the last K source rows
     auto hpass = [&](us2 (&h)[8], WR& W) {
         fix_edges<C, R>(W, first, last);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int p = slot_p(s);
-            if (K == 3) {
-                h[s] = (fld<C, R>(W, p - C) + fld<C, R>(W, p + C)) + fld<C, R>(W, p) * kx1;
-            } else {
-                const us2 o = fld<C, R>(W, p - 2 * C) + fld<C, R>(W, p + 2 * C);
-                const us2 i = fld<C, R>(W, p - C) + fld<C, R>(W, p + C);
-                h[s] = (o + i * kx1) + fld<C, R>(W, p) * kx2;
-            }
-        }
+        pow2_rowpass<C, K>(h, W, kx1, kx2);
     };
     WR nx[K];
 #pragma unroll
@@ -507,22 +540,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void sep_pow2_kernel(const 
             load_win<C, R>(nx[slot], row(tt + K), b0, g.L);
             const int yo = tt - (K - 1);
             if (yo < nrows) {
-                us2 o[8];
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {                    // source rows yo .. yo + K - 1 = ring slots (slot + 1 + i) % K
-                    us2 v;
-                    if (K == 3) {
-                        v = (hb[(slot + 1) % K][s] + hb[slot][s]) + (hb[(slot + 2) % K][s] * ky1 + rnd);
-                    } else {
-                        const us2 oo = hb[(slot + 1) % K][s] + hb[slot][s];
-                        const us2 ii = hb[(slot + 2) % K][s] + hb[(slot + 4) % K][s];
-                        v = (oo + ii * ky1) + (hb[(slot + 3) % K][s] * ky2 + rnd);
-                    }
-                    o[s] = v >> sh;
-                }
-                u32x4 ov;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) ov[k] = pack_fields(o[2 * k], o[2 * k + 1]);
+                const u32x4 ov = pow2_colpass<K>(hb, slot, ky1, ky2, rnd, sh);
                 st16_nt(dimg + (int64_t)(y0 + yo) * g.d_row + b0, ov);
             }
         }
@@ -622,17 +640,7 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
         WR W;
         band_win<C, R>(W, s_tile, bg.pitch, r, off, lo, hi);
         fix_edges<C, R>(W, first, last);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int p = slot_p(s);
-            if (K == 3) {
-                h[s] = (fld<C, R>(W, p - C) + fld<C, R>(W, p + C)) + fld<C, R>(W, p) * kx1;
-            } else {
-                const us2 o = fld<C, R>(W, p - 2 * C) + fld<C, R>(W, p + 2 * C);
-                const us2 i = fld<C, R>(W, p - C) + fld<C, R>(W, p + C);
-                h[s] = (o + i * kx1) + fld<C, R>(W, p) * kx2;
-            }
-        }
+        pow2_rowpass<C, K>(h, W, kx1, kx2);
     };
 #pragma unroll
     for (int j = 0; j < K - 1; ++j) hrow(hb[j], j);
@@ -645,22 +653,7 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
             const int yo = tt - (K - 1);
             if (yo < nrows) {
                 hrow(hb[slot], tt);
-                us2 o[8];
-#pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    us2 v;
-                    if (K == 3) {
-                        v = (hb[(slot + 1) % K][s] + hb[slot][s]) + (hb[(slot + 2) % K][s] * ky1 + rnd);
-                    } else {
-                        const us2 oo = hb[(slot + 1) % K][s] + hb[slot][s];
-                        const us2 ii = hb[(slot + 2) % K][s] + hb[(slot + 4) % K][s];
-                        v = (oo + ii * ky1) + (hb[(slot + 3) % K][s] * ky2 + rnd);
-                    }
-                    o[s] = v >> sh;
-                }
-                u32x4 ov;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) ov[k] = pack_fields(o[2 * k], o[2 * k + 1]);
+                const u32x4 ov = pow2_colpass<K>(hb, slot, ky1, ky2, rnd, sh);
                 st16_nt(dimg + (int64_t)(bt.y0 + yo) * g.d_row + b0, ov);
             }
         }
