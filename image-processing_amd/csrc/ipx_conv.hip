@@ -1114,7 +1114,11 @@ int make_band_geom(BandGeom& bg, const ConvGeom& g, int n, int band_rows)
     bg.g = g;
     bg.band_rows = band_rows;
     bg.nbands = (g.h + band_rows - 1) / band_rows;
-    bg.ntx = (g.nlanes + kBandLanes - 1) / kBandLanes;
+    int maxl = kBandLanes;
+#ifdef IPX_DEV
+    maxl = env_int("IPX_BAND_LANES", kBandLanes);                 // development: narrower tiles (64, 128, 192)
+#endif
+    bg.ntx = (g.nlanes + maxl - 1) / maxl;
     bg.tile_lanes = ((g.nlanes + bg.ntx - 1) / bg.ntx + 63) / 64 * 64;   // near-equal widths in whole waves (1080p BGR: 192 + 168 lanes,
                                                                   // not 256 + 104; 4K BGR: 256 + 256 + 208)
     bg.pitch = 16 * bg.tile_lanes + 64;
@@ -1273,7 +1277,8 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     ) {                                                               // cv2.GaussianBlur's own 3- and 5-tap kernels
         // rows of whole 16-byte lanes, at least one full 4 KiB tile wide: LDS band tiles (5-10 % faster than the strip
         // walker on BGR frames: 229 vs 248 us for 5 taps, 206 vs 232 us for 3 taps per 24 x 4K, scripts/dev/bandab.py)
-        int band = g.L % 16 == 0 && g.nlanes >= 256 ? (k == 3 ? 8 : 12) : 0;   // 3 taps: 3 blocks of 41 KiB per CU; 5 taps: 2 of 66 KiB
+        int band = g.L % 16 == 0 && g.nlanes >= 256 ? 8 : 0;   // 3 blocks of 41 KiB (3 taps) / 49 KiB (5 taps) per CU; 12-row tiles (66 KiB,
+                                                               // 2 blocks) are as fast alone but 1 % slower inside the step
         if (k == 5) {
             // 5 taps gain little (2-5 % on 4K / 8K rows) and only when the equal-width tiles fill the block's four waves:
             // on 1080p BGR rows (2 tiles of 180 lanes) the walker is as fast per launch and 2-4 % faster in a pipeline
