@@ -92,7 +92,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=24, help="4K RGB frames per GPU per step (8: 325 k, 16: 364 k, 24: 379 k, 32: 373 k, 64: 365 k MP/s)")
     ap.add_argument("--cpu-sample", type=int, default=250, help="passes of the CPU oracle over 4 frames, ~15 s of CPU work, capped at 30 s (0 = skip)")
-    ap.add_argument("--order", default="gauss_first", choices=["gauss_first", "geq_first", "sobel_mid"], help="order of the three independent ops inside a step")
+    ap.add_argument("--order", default="sobel_mid", choices=["sobel_mid", "table_first", "gauss_last"],
+                    help="order of the step's four launches (same kernels, same results): sobel_mid = Gaussian, BGR->gray+histogram, "
+                         "Sobel, equalize table pass (Sobel reads the gray batch right after it was written); table_first = the "
+                         "round-1 order (equalize finished before Sobel); gauss_last = sobel_mid with the Gaussian at the end")
     ap.add_argument("--ops-table", action="store_true", help="also time ops that are not part of the step, back to back")
     args = ap.parse_args()
 
@@ -134,11 +137,12 @@ def main():
 
     STEP_OPS = [  # name, kernels, algorithmic bytes per pixel
         ("gaussian5_bgr", "sep_pow2_band_kernel<3,5>", 6),
-        ("bgr2gray_equalize", "gray_hist_kernel<3>+hist_finish_kernel+lut_kernel", 6),
+        ("bgr2gray_hist", "gray_hist_kernel<3>+hist_finish_kernel", 4),      # cvtColor + histogram + equalize table (server.py:245-246, first half)
         ("sobel3_gray", "conv3_kernel<SOBEL,1>", 2),
+        ("equalize_table_pass", "lut_kernel", 2),                            # cv2.equalizeHist's second half: dst = table[gray]
     ]
 
-    ORDERS = {"geq_first": (1, 0, 2), "gauss_first": (0, 1, 2), "sobel_mid": (1, 2, 0)}
+    ORDERS = {"sobel_mid": (0, 1, 2, 3), "table_first": (0, 1, 3, 2), "gauss_last": (1, 2, 3, 0)}
     order = ORDERS[args.order]
     STEP_OPS = [STEP_OPS[i] for i in order]
 
@@ -149,8 +153,10 @@ def main():
         recorded on the stream the kernels are launched on (torch's current stream): around every op, or with `only`
         around that op alone (ev[0], ev[1]).  An event between two kernels keeps them from overlapping at their edges
         (measured: 4 events per step cost 2-3 % of the step, scripts/dev/evprobe.py), so the timed region carries only
-        the two around the dominant kernel.  The three ops are independent except that Sobel needs the gray image;
-        --order only changes which runs first."""
+        the two around the dominant kernel.  cvtColor + equalizeHist is the fused entry point split at its own seam
+        (ipx_bgr2gray_equalize_u8 with dst = NULL, then ipx_lut_dev_u8 with the tables it produced): the same kernels as the
+        fused call, with Sobel free to run between them, where the gray batch it reads has just been written (step 483 us
+        against 495 us, scripts/dev/orderab.py).  --order only changes which launch runs when."""
         res = {}
         src = bgr if src is None else src
         if ev is not None and only is None:
@@ -161,9 +167,11 @@ def main():
             if i == 0:
                 res["g5"] = ops.gaussian_blur(src, 5)
             elif i == 1:
-                res["gray"], res["eq"] = ops.bgr2gray_equalize(src)   # cvtColor + equalizeHist, histogram taken while gray is written
-            else:
+                res["gray"], _, res["lut"] = ops.bgr2gray_hist(src)   # cvtColor, histogram taken while gray is written, equalize tables
+            elif i == 2:
                 res["sb"] = ops.sobel(res["gray"])
+            else:
+                res["eq"] = ops.apply_lut_dev(res["gray"], res["lut"])
             if ev is not None and only is None:
                 ev[j + 1].record()
             if ev is not None and only == i:
@@ -191,18 +199,35 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     # the same K steps once more, instrumented around every op (outside the timed region): the per-op table
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
     for i in range(args.steps):
         step(events[i])
     torch.cuda.synchronize()
     # the LITERAL configs[1]: ONE 4K image per launch (what a single /api/process request sees); same event scheme
     one = bgr[:1]
     lat_steps = 50
+    LAT_OPS = ("gaussian5_bgr", "bgr2gray_equalize", "sobel3_gray")
+
+    def step_one(ev=None):
+        """what three single requests do: the Gaussian, the FUSED cvtColor + equalizeHist call, Sobel (with one image per
+        launch the host's enqueue time shows between the events, so the step's four-launch form would only add to it)"""
+        if ev is not None:
+            ev[0].record()
+        ops.gaussian_blur(one, 5)
+        if ev is not None:
+            ev[1].record()
+        gray1, _ = ops.bgr2gray_equalize(one)
+        if ev is not None:
+            ev[2].record()
+        ops.sobel(gray1)
+        if ev is not None:
+            ev[3].record()
+
     for _ in range(5):
-        step(src=one)
+        step_one()
     lat_events = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(lat_steps)]
     for i in range(lat_steps):
-        step(lat_events[i], src=one)
+        step_one(lat_events[i])
     torch.cuda.synchronize()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -243,8 +268,12 @@ def main():
             else:
                 s = sum(events[i][j].elapsed_time(events[i][j + 1]) for i in range(args.steps)) / args.steps * 1e-3
                 kernels[name] = row(kern, bpp, s, "HIP events around every op in K instrumented steps after the timed region (in-pipeline)")
+        # cvtColor + equalizeHist as ONE op (the round-1 table's key): its two halves added up
+        a, b = kernels["bgr2gray_hist"], kernels["equalize_table_pass"]
+        kernels["bgr2gray_equalize"] = row(a["kernel"] + "+" + b["kernel"], 6, (a["us_per_launch"] + b["us_per_launch"]) * 1e-6,
+                                           "sum of bgr2gray_hist and equalize_table_pass above")
         latency_b1_us = {}
-        for j, (name, _, _) in enumerate(STEP_OPS):
+        for j, name in enumerate(LAT_OPS):
             ts = sorted(lat_events[i][j].elapsed_time(lat_events[i][j + 1]) for i in range(lat_steps))
             latency_b1_us[name] = round(ts[len(ts) // 2] * 1e3, 1)
         ts = sorted(lat_events[i][0].elapsed_time(lat_events[i][3]) for i in range(lat_steps))
@@ -304,6 +333,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: 3840x2160 RGB, 5x5 Gaussian + Sobel (3x3) + hist-eq "
                                    "(incl. BGR->gray), batch resident in HBM",
                        "batch_per_gpu": B, "image": "3840x2160x3 u8 BGR interleaved",
+                       "launch_order": [STEP_OPS[j][0] for j in range(len(STEP_OPS))],
                        "parallelism": f"{world} x one process per GPU, images sharded, no collective"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "latency_b1_us": latency_b1_us,
         }

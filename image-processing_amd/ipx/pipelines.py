@@ -75,7 +75,10 @@ def full_pipeline(ops, bgr) -> dict:
 
 
 def configs1_step(ops, bgr):
-    """BASELINE.json configs[1]: 5x5 Gaussian (BGR) + hist-eq (incl. BGR->gray) + Sobel on the gray image."""
+    """BASELINE.json configs[1]: 5x5 Gaussian (BGR) + hist-eq (incl. BGR->gray) + Sobel on the gray image.  cvtColor +
+    equalizeHist run as the fused entry point's two halves with Sobel between them: Sobel then reads the gray batch right
+    after it was written (same kernels and results as bgr2gray_equalize followed by sobel, 2.5 % less time per step)."""
     g5 = ops.gaussian_blur(bgr, 5)
-    gray, eq = ops.bgr2gray_equalize(bgr)
-    return g5, eq, ops.sobel(gray)
+    gray, _, lut = ops.bgr2gray_hist(bgr)
+    sb = ops.sobel(gray)
+    return g5, ops.apply_lut_dev(gray, lut), sb

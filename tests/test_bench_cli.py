@@ -35,3 +35,4 @@ def test_gpus_2_starts_two_ranks(dev):
     assert j["n_gpus"] == 2 and j["config"]["batch_per_gpu"] == 4 and j["value"] > 0
     assert j["scaling"] == "weak" and j["cpu_baseline"] is None
     assert set(j["latency_b1_us"]) >= {"gaussian5_bgr", "bgr2gray_equalize", "sobel3_gray", "step"}
+    assert set(j["kernels"]) >= {"gaussian5_bgr", "bgr2gray_hist", "equalize_table_pass", "bgr2gray_equalize", "sobel3_gray"}
