@@ -88,7 +88,7 @@ def spawn_ranks(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=24, help="4K RGB frames per GPU per step (8: 325 k, 16: 364 k, 24: 379 k, 32: 373 k, 64: 365 k MP/s)")
     ap.add_argument("--cpu-sample", type=int, default=250, help="passes of the CPU oracle over 4 frames, ~15 s of CPU work, capped at 30 s (0 = skip)")
