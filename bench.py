@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=24, help="4K RGB frames per GPU per step (8: 325 k, 16: 364 k, 24: 379 k, 32: 373 k, 64: 365 k MP/s)")
+    ap.add_argument("--batch", type=int, default=24, help="4K RGB frames per GPU per step (round 2: 8: 353 k, 16: 382 k, 20: 400 k, 24: 408 k, 32: 410 k, 48: 397 k MP/s; beyond 24 frames the gray batch no longer fits the Infinity Cache between the kernels that write and read it)")
     ap.add_argument("--cpu-sample", type=int, default=250, help="passes of the CPU oracle over 4 frames, ~15 s of CPU work, capped at 30 s (0 = skip)")
     ap.add_argument("--order", default="sobel_mid", choices=["sobel_mid", "table_first", "gauss_last"],
                     help="order of the step's four launches (same kernels, same results): sobel_mid = Gaussian, BGR->gray+histogram, "
