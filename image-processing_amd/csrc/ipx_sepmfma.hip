@@ -31,10 +31,18 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int TY = 64, TX = 128, kThreads = 512;       // 8 waves per tile: 3 resident blocks = 24 waves per CU
 constexpr int kRowsS = 96;                       // 6 M-tiles of source rows (64 + 2*15 = 94 exist at most)
-constexpr int kPitchH = 96;                      // bytes per HT column = the 96 row-pass rows; 32 mod 64 makes the column
-                                                 // pass's ds_read_b128 conflict-free (lane groups of MI355X_MICROARCH.md
-                                                 // section LDS).  Its last k-chunk (rows 96..111, zero taps) reads on into
-                                                 // the next column / the bytes behind the plane: finite garbage times zero
+constexpr int kPitchHRot = 128, kPitchHPlain = 96;  // bytes per HT column.
+// Plain (96 = 32 mod 64): the column pass's ds_read_b128 are conflict-free in every lane group of MI355X_MICROARCH.md section
+// LDS, but the row pass's ds_write_b32 are 4-way (banks (24 m + gq) mod 32).  Rotated (128 = 8 chunks of 16 rows, 6 of them
+// hold the 96 row-pass rows): column 16 w + m keeps its chunk c at position (c + rot(m)) mod 8, rot(m) = (m & 3) + 4 (m >> 3);
+// reads stay conflict-free, stores become 2-way (free for stores), and the hi / lo stores of a lane (planes 64 x 256 B apart)
+// merge into one ds_write2st64_b32 (scripts/dev/ldsbanks.py enumerates pitches and rotations; none exists for a pitch below
+// 128).  Measured: 3-5 % (9 taps on 2 x 8K BGR 116-120 us against 121-123, 15 taps ~140 against ~150) -- LDS cycles are not what
+// bounds this kernel.  The rotated planes cost 8 KiB more, and LDS is handed out in granules of 1280 bytes: three blocks per CU
+// need <= 42 granules = 53,760 bytes each (53,824 already run two per CU: 31 taps 160 -> 186 us).  So the rotation is used where
+// the source tile is small enough (k <= 17: 80 rows); 19-31 taps (94 rows, 53,824 bytes with it) and 64-byte halos stay plain.
+// The column pass's last k-chunk (rows 96..111, zero taps) reads finite garbage: the next column / the bytes behind the plane
+// (plain), or a never-written chunk of the same column (rotated).
 constexpr int kPitchO = 144;                     // result staging pitch (pitch/4 = 4 mod 8, multiple of 16)
 
 struct MGeom {
@@ -78,10 +86,12 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
     constexpr int SW = TX + 2 * HL;                              // source tile width in bytes
     constexpr int PS = HL <= 48 ? 224 : 288;                     // source pitch: >= SW and = 32 mod 64: conflict-free b128 reads
     constexpr int NCH = SW / 16;
+    constexpr int kPitchH = (HL > 48 || NMT != 5) ? kPitchHPlain : kPitchHRot;
+    constexpr bool ROT = kPitchH == kPitchHRot;
     constexpr int NLD = kRowsS / 32;                             // source rows per thread: rows (tid >> 4) + 32 i
     // one LDS block: source tile (also the result staging tile) | the two transposed planes | taps.  Only TY + 30 = 94
     // source rows exist; the row pass's last 16-row tile and its k-step padding read on into the planes (times zero taps)
-    constexpr int kSrcBytes = (TY + 30) * PS;
+    constexpr int kSrcBytes = (NMT == 5 ? 80 : TY + 30) * PS;    // k <= 17: 64 + 2 * 8 = 80 rows at most
     __shared__ __attribute__((aligned(16))) uint8_t s_all[kSrcBytes + 2 * TX * kPitchH + 64 + 16];
     uint8_t* const s_src = s_all;
     uint8_t* const s_ht0 = s_all + kSrcBytes;
@@ -202,10 +212,11 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
     // per-lane LDS addresses (tile independent)
     uint8_t* const st_src = s_src + lrow * PS + 16 * lch;                       // source staging: + 32 i PS
     const uint8_t* const a_h = s_src + m * PS + 16 * gq + 16 * wave;            // row pass A: + 16 mt PS + 64 q
-    uint8_t* const w_hi = s_ht0 + (16 * wave + m) * kPitchH + 4 * gq;           // row pass result: + 16 mt
-    uint8_t* const w_lo = s_ht1 + (16 * wave + m) * kPitchH + 4 * gq;
-    const uint8_t* const a_vhi = s_ht0 + (16 * wave + m) * kPitchH;             // column pass A: + 16 (nt + gq)
-    const uint8_t* const a_vlo = s_ht1 + (16 * wave + m) * kPitchH;
+    const int rot = ROT ? (m & 3) + 4 * (m >> 3) : 0;                           // chunk rotation of column 16 w + m (see kPitchHRot)
+    uint8_t* const w_hi = s_ht0 + (16 * wave + m) * kPitchH + 4 * gq;           // row pass result: + 16 ((mt + rot) & 7); lo plane:
+    constexpr int kPlane = TX * kPitchH;                                        // + kPlane (= 64 x 256 B: one ds_write2st64_b32)
+    const uint8_t* const a_vhi = s_ht0 + (16 * wave + m) * kPitchH;             // column pass A: + 16 ((nt + gq + rot) & 7)
+    const int rrot = gq + rot;
     uint8_t* const s_out = s_src;
     uint8_t* const w_out = s_out + m * kPitchO + 16 * wave + 4 * gq;            // + 16 nt kPitchO
     const int orow = tid >> 3, occ = tid & 7;                                   // output chunk: row orow (0..63)
@@ -248,8 +259,9 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
         const uint32_t h0 = (uint32_t)acc[0], h1 = (uint32_t)acc[1], h2 = (uint32_t)acc[2], h3 = (uint32_t)acc[3];
         const uint32_t hi = __builtin_amdgcn_perm(h1, h0, 0x0c0c0501u) | __builtin_amdgcn_perm(h3, h2, 0x05010c0cu);
         const uint32_t lo = (__builtin_amdgcn_perm(h1, h0, 0x0c0c0400u) | __builtin_amdgcn_perm(h3, h2, 0x04000c0cu)) ^ 0x80808080u;
-        *reinterpret_cast<uint32_t*>(w_hi + 16 * mt) = hi;
-        *reinterpret_cast<uint32_t*>(w_lo + 16 * mt) = lo;
+        uint8_t* const wp = w_hi + 16 * (ROT ? (mt + rot) & 7 : mt);
+        *reinterpret_cast<uint32_t*>(wp) = hi;
+        *reinterpret_cast<uint32_t*>(wp + kPlane) = lo;
     }
     lds_barrier();
 
@@ -260,9 +272,9 @@ __global__ __launch_bounds__(kThreads, 6) void sep_mfma_kernel(const uint8_t* __
     for (int nt = 0; nt < TY / 16; ++nt) {
         constexpr int c0 = 32768 * 256 + 32768 + 32768;          // rounding and the two +2^15 offsets, via the accumulator
         const v4i z = {0, 0, 0, 0}, zc = {c0, c0, c0, c0};
-        const int vo = 16 * (nt + gq);
+        const int vo = 16 * (ROT ? (nt + rrot) & 7 : nt + rrot);
         const v4i dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_vhi + vo), bv, z, 0, 0, 0);
-        const v4i dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_vlo + vo), bv, zc, 0, 0, 0);
+        const v4i dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(lds16(a_vhi + kPlane + vo), bv, zc, 0, 0, 0);
         uint32_t o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] = ((uint32_t)dhi[i] << 8) + (uint32_t)dlo[i];
