@@ -448,7 +448,8 @@ __global__ __launch_bounds__(K <= 5 ? 64 * kMaxWavesPerBlock : 512) void sep_sma
 // (256-scaled sum + 2^15) >> 16 == (S + 2^(15 - m)) >> (16 - m).  Symmetry (outer tap 1) halves the multiplies:
 // (a + e) + k1 (b + d) + k2 c is two packed adds and two packed multiply-adds for two pixels, in both passes -- about
 // 100 vector instructions per 16 bytes and row against 150 for the general kernel (v_pk_mad_u16 row pass, v_dot2 column
-// pass on row pairs), which is bound by vector issue, not by memory (SQ_WAIT_INST_ANY 59 %, profiles/r02_notes.md).
+// pass on row pairs).  On gray frames that is 10 % faster (75 against 83 us per 24 x 4K); on BGR frames it is not -- the walker's
+// access pattern, not its instruction count, bounds it there (profiles/r02_notes.md).
 struct Pow2Taps { uint32_t kx1, kx2, ky1, ky2, rnd, sh; };       // inner taps (K = 3: k1 = centre, k2 unused), rounding, shift
 
 // Row pass and column pass of the packed filter, shared by the strip walker and the band-tile kernel.
