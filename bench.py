@@ -302,7 +302,7 @@ def main():
                 ("erode_3", "morph_small_kernel<false,1>", 2, lambda: ops.erode(gray, ops.ellipse_se(3))),
                 ("dilate_5", "morph_small_kernel<true,2>", 2, lambda: ops.dilate(gray, ops.ellipse_se(5))),
                 ("median_3", "median3_kernel", 2, lambda: ops.median_blur(gray, 3)),
-                ("median_5", "median_small_kernel<5>", 2, lambda: ops.median_blur(gray, 5)),
+                ("median_5", "median5_kernel", 2, lambda: ops.median_blur(gray, 5)),
                 ("median_31", "median_hist_kernel", 2, lambda: ops.median_blur(gray, 31)),
             ]:
                 kernels[name] = row(kern, bpp, time_op(fn), "20 back-to-back launches between two HIP events")

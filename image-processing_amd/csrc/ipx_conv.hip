@@ -896,6 +896,120 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void median3_kernel(const u
     }
 }
 
+// ---- 5 x 5 median (cv2.medianBlur(gray, 5), server.py:436 with denoise_manual's default kernel) on the strip walker ----
+// Gray images, BORDER_REPLICATE.  The min / max network comes from scripts/gen_median5_net.py (verified there and in
+// tests/test_median5_net.py on all 2^25 0-1 inputs) and is built so that neighbouring windows share most of it:
+//   A) every column's 5 vertical values are sorted once (a column belongs to 5 windows),
+//   B) the sorted columns (2i, 2i + 1) are merged into sorted 10-lists once (such a pair belongs to 4 windows),
+//   C) a window takes its two pairs and its fifth column: columns x-2 .. x+2 for even x are pairs (x-2, x-1), (x, x+1)
+//      and column x+2; for odd x they are column x-2 and pairs (x-1, x), (x+1, x+2).
+// On field pairs (byte p, byte p+2): E_d = bytes (4d, 4d+2) and O_d = bytes (4d+1, 4d+3) of dword d sort as two columns
+// each, merge(E_d, O_d) = P_d holds pairs (4d, 4d+1) | (4d+2, 4d+3), and the lists a window needs that straddle two dwords
+// are v_alignbit_b32 of neighbouring P (Q_d = P_d.hi | P_d+1.lo) or sorted columns.  Per 16 pixels: 12 column sorts,
+// 6 merges, 8 selections = 216 + 156 + 368 packed min / max and ~100 moves and shifts -- 53 per pixel, where the tile
+// kernel in ipx_rank.hip spends 2 x 120 on a from-scratch selection per pixel pair.
+#define M5_T us2
+#define M5_MIN(a, b) __builtin_elementwise_min(a, b)
+#define M5_MAX(a, b) __builtin_elementwise_max(a, b)
+#define M5_FN __device__ __forceinline__
+#include "ipx_median5_net.inc"
+#undef M5_T
+#undef M5_MIN
+#undef M5_MAX
+#undef M5_FN
+
+__device__ __forceinline__ us2 hi_lo(us2 left, us2 right)        // (left's high half, right's low half): one v_alignbit_b32
+{
+    return __builtin_bit_cast(us2, __builtin_amdgcn_alignbit(__builtin_bit_cast(uint32_t, right), __builtin_bit_cast(uint32_t, left), 16));
+}
+
+template <int PF>
+__global__ __launch_bounds__(256) void median5_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, ConvGeom g)
+{
+    constexpr int K = 5, ND = 6;                                 // dwords d = 0 .. 5 of the window: row bytes b0 - 4 .. b0 + 19
+    constexpr int NR = 2 * ND;                                   // field pairs per row: E_d, O_d
+    typedef Win<1, 2> WR;
+    static_assert(WR::ND == ND, "one halo dword on either side");
+    unsigned img; int y0, y1, lane0;
+    if (!wave_item(g, img, y0, y1, lane0)) return;
+    const int gl = lane0 + (int)(threadIdx.x & 63u);
+    if (gl >= g.nlanes) return;
+    const int b0 = lane_b0(g, gl);
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    const int nrows = y1 - y0;
+    auto row = [&](int t) {                                      // walk step t = source row y0 - 2 + t, replicated at the ends
+        int yy = y0 - 2 + t;
+        yy = yy < 0 ? 0 : yy > g.h - 1 ? g.h - 1 : yy;
+        return simg + (int64_t)yy * g.s_row;
+    };
+    auto even = [](uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c020c00u); };   // bytes (0, 2) as 2 x u16
+    auto odd = [](uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c01u); };    // bytes (1, 3)
+    uint32_t ring[K][NR];                                        // the field pairs of the last 5 source rows (raw dwords in the
+                                                                 // ring and fields per step: 149 instead of 130 VGPRs and 1 % slower)
+    auto settle = [&](uint32_t (&o)[NR], WR& W) {
+        if (first) W.w[0] = (W.w[1] & 255u) * 0x01010101u;       // bytes -4 .. -1 = byte 0
+        if (last) W.w[5] = (W.w[4] >> 24) * 0x01010101u;         // bytes 16 .. 19 = byte 15
+#pragma unroll
+        for (int d = 0; d < ND; ++d) { o[2 * d] = even(W.w[d]); o[2 * d + 1] = odd(W.w[d]); }
+    };
+    {
+        WR w0[K - 1];
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) load_win<1, 2>(w0[j], row(j), b0, g.L);
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) settle(ring[j + 1], w0[j]);
+    }
+    WR nx[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) load_win<1, 2>(nx[j], row(K - 1 + j), b0, g.L);
+    for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = t0 + u, yo = t - (K - 1);
+            if (yo >= nrows) break;                              // wave-uniform
+#pragma unroll
+            for (int r = 0; r < K - 1; ++r) {
+#pragma unroll
+                for (int d = 0; d < NR; ++d) ring[r][d] = ring[r + 1][d];
+            }
+            settle(ring[K - 1], nx[u]);
+            load_win<1, 2>(nx[u], row(t + PF), b0, g.L);
+            us2 sE[ND][5], sO[ND][5], P[ND][10], Q[ND - 1][10];
+            u32x4 ov;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    sE[d][r] = __builtin_bit_cast(us2, ring[r][2 * d]);
+                    sO[d][r] = __builtin_bit_cast(us2, ring[r][2 * d + 1]);
+                }
+                med5_sort5(sE[d]);
+                med5_sort5(sO[d]);
+                med5_merge(sE[d], sO[d], P[d]);
+                if (d >= 1) {
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) Q[d - 1][i] = hi_lo(P[d - 1][i], P[d][i]);
+                }
+                if (d >= 2) {                                    // output dword e = d - 1 (window dword index; row bytes 4 (e - 1) ..)
+                    const int e = d - 1;
+                    us2 ce[5], co[5];
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        ce[r] = hi_lo(sE[e][r], sE[e + 1][r]);   // columns 4j + 2 | 4j + 4 for the windows at 4j | 4j + 2
+                        co[r] = hi_lo(sO[e - 1][r], sO[e][r]);   // columns 4j - 1 | 4j + 1 for the windows at 4j + 1 | 4j + 3
+                    }
+                    const us2 oe = med5_select(Q[e - 1], P[e], ce);
+                    const us2 oo = med5_select(P[e], Q[e], co);
+                    ov[e - 1] = pack_fields(oe, oo);
+                }
+            }
+            st16_nt(dimg + (int64_t)(y0 + yo) * g.d_row + b0, ov);
+        }
+    }
+}
+
 // ---- generic two-pass path (any odd K <= IPX_MAX_GAUSS_K) -----------------------------------------------
 struct TapsBig { uint16_t k[IPX_MAX_GAUSS_K + 1]; };
 
@@ -1220,6 +1334,19 @@ int ipx_median3_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, 
     if (g.nlanes == 0) return 0;
     hipLaunchKernelGGL(median3_kernel, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
     if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median3_kernel failed");
+    return 1;
+}
+
+// Called by ipx_median_blur_u8 for k = 5, same contract.
+int ipx_median5_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                       int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img)
+{
+    constexpr int PF = 2;                                        // rows in flight per lane (3: 2 % slower)
+    ConvGeom g;
+    if (int rc = make_conv_geom("ipx_median_blur_u8", g, src, dst, n, h, w, 1, 2, 4, PF, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
+    if (g.nlanes == 0) return 0;
+    hipLaunchKernelGGL(median5_kernel<PF>, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
+    if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median5_kernel failed");
     return 1;
 }
 

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Dev: time cv2.medianBlur's k = 3 / 5 / 7 kernels on the bench's gray batch (24 x 4K) and on 128 x 1080p."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "image-processing_amd"))
+import torch
+from ipx import ops
+
+def time_op(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+dev = torch.device("cuda:0")
+for n, h, w in ((24, 2160, 3840), (128, 1080, 1920)):
+    g = torch.randint(0, 256, (n, h, w, 1), dtype=torch.uint8, device=dev)
+    for _ in range(30): ops.median_blur(g, 3)
+    for k in (3, 5, 7):
+        us = time_op(lambda: ops.median_blur(g, k))
+        print(f"{n} x {w}x{h} median k={k}: {us:8.1f} us  {2 * n * h * w / us / 1e3:7.1f} GB/s algorithmic", flush=True)

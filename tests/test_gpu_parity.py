@@ -511,19 +511,27 @@ def test_median_extremes_and_batch(dev):
         np.testing.assert_array_equal(got[i, :, :, 0], O.median_blur_u8(batch[i, :, :, 0], 5))
 
 
-def test_median3_strip_walker(dev):
-    """k = 3 on rows long enough for the strip walker (sorted columns): widths around the 16-byte lane and 1 KiB strip
-    boundaries, heights around the row segments, few grey levels (many ties), a strided batch with an unaligned base."""
-    rng = np.random.default_rng(33)
-    for h, w in ((1, 36), (2, 47), (3, 48), (7, 49), (25, 64), (26, 1023), (50, 1024), (49, 1041), (130, 2051), (5, 4099)):
+@pytest.mark.parametrize("k", [3, 5])
+def test_median_strip_walkers(dev, k):
+    """k = 3 and k = 5 on rows long enough for the strip walkers (sorted columns; shared pair merges for k = 5): widths
+    around the 16-byte lane and 1 KiB strip boundaries, heights around the row segments and below the window, few grey
+    levels (many ties), ramps and their mirror images (every rank order of a window's columns), a strided batch with an
+    unaligned base."""
+    rng = np.random.default_rng(33 + k)
+    for h, w in ((1, 36), (2, 47), (3, 48), (4, 40), (7, 49), (25, 64), (26, 1023), (50, 1024), (49, 1041), (130, 2051), (5, 4099)):
         for levels in (256, 3):
             img = (rng.integers(0, levels, (h, w)) * (255 // (levels - 1))).astype(np.uint8)
-            np.testing.assert_array_equal(host(ops.median_blur(dev_t(img, dev), 3)), O.median_blur_u8(img, 3), err_msg=f"{h}x{w}")
+            np.testing.assert_array_equal(host(ops.median_blur(dev_t(img, dev), k)), O.median_blur_u8(img, k), err_msg=f"{h}x{w}")
+    yy, xx = np.mgrid[0:70, 0:1100]
+    for img in ((xx * 3 + yy * 5) % 256, (xx * 7 - yy * 11) % 256, (xx * yy) % 251, np.where((xx // 3 + yy // 2) % 2, 255, 0)):
+        img = img.astype(np.uint8)
+        for v in (img, img[::-1].copy(), img[:, ::-1].copy()):
+            np.testing.assert_array_equal(host(ops.median_blur(dev_t(v, dev), k)), O.median_blur_u8(v, k))
     big = rng.integers(0, 256, (3, 60, 700), dtype=np.uint8)
     view = dev_t(big, dev)[:, 5:55, 3:3 + 611].unsqueeze(-1)
-    got = host(ops.median_blur(view, 3))
+    got = host(ops.median_blur(view, k))
     for i in range(3):
-        np.testing.assert_array_equal(got[i, :, :, 0], O.median_blur_u8(np.ascontiguousarray(big[i, 5:55, 3:614]), 3))
+        np.testing.assert_array_equal(got[i, :, :, 0], O.median_blur_u8(np.ascontiguousarray(big[i, 5:55, 3:614]), k))
 
 
 @pytest.mark.parametrize("k", [9, 11, 13, 21, 31])

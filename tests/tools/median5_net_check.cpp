@@ -1,0 +1,72 @@
+// Runs the EMITTED text of image-processing_amd/csrc/ipx_median5_net.inc on the CPU (test infrastructure, not product):
+//   1) all 2^25 0-1 inputs, 64 patterns per machine word (min = and, max = or), composed exactly as median5_kernel
+//      composes the pieces: five column sorts, two pair merges, the selection;
+//   2) random byte windows (many ties) against std::nth_element.
+// Prints "ok" and exits 0, or says what failed.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+namespace bits {
+#define M5_T uint64_t
+#define M5_MIN(a, b) ((a) & (b))
+#define M5_MAX(a, b) ((a) | (b))
+#define M5_FN static inline
+#include "ipx_median5_net.inc"
+#undef M5_T
+#undef M5_MIN
+#undef M5_MAX
+#undef M5_FN
+}
+namespace vals {
+#define M5_T int
+#define M5_MIN(a, b) std::min(a, b)
+#define M5_MAX(a, b) std::max(a, b)
+#define M5_FN static inline
+#include "ipx_median5_net.inc"
+}
+
+template <typename T, typename S, typename M, typename Q>
+static T median25(const T (&in)[25], S sort5, M merge, Q select)
+{
+    T col[5][5];
+    for (int c = 0; c < 5; ++c) {
+        for (int r = 0; r < 5; ++r) col[c][r] = in[5 * c + r];
+        sort5(col[c]);
+    }
+    T p[10], q[10];
+    merge(col[0], col[1], p);
+    merge(col[2], col[3], q);
+    return select(p, q, col[4]);
+}
+
+int main()
+{
+    static const uint64_t low[6] = {0xaaaaaaaaaaaaaaaaull, 0xccccccccccccccccull, 0xf0f0f0f0f0f0f0f0ull,
+                                    0xff00ff00ff00ff00ull, 0xffff0000ffff0000ull, 0xffffffff00000000ull};
+    for (uint32_t blk = 0; blk < (1u << 19); ++blk) {
+        uint64_t in[25], cnt[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < 25; ++i) {
+            in[i] = i < 6 ? low[i] : ((blk >> (i - 6)) & 1u) ? ~0ull : 0ull;
+            uint64_t c = in[i];
+            for (int b = 0; b < 5; ++b) { const uint64_t t = cnt[b] & c; cnt[b] ^= c; c = t; }
+        }
+        // ones >= 13  <=>  bit 4 set, or bit 3 set and (bit 2 set and (bit 1 or bit 0))
+        const uint64_t want = cnt[4] | (cnt[3] & cnt[2] & (cnt[1] | cnt[0]));
+        const uint64_t got = median25(in, bits::med5_sort5, bits::med5_merge, bits::med5_select);
+        if (got != want) { std::printf("0-1 block %u differs: %016llx vs %016llx\n", blk, (unsigned long long)got, (unsigned long long)want); return 1; }
+    }
+    uint32_t s = 12345u;
+    for (int it = 0; it < 2000000; ++it) {
+        int in[25], srt[25];
+        s = s * 1664525u + 1013904223u;
+        const int range = 1 + (int)((s >> 24) % 5u == 0 ? 3 : (s >> 16) & 255u);     // a fifth of the cases: values 0..3 (ties)
+        for (int i = 0; i < 25; ++i) { s = s * 1664525u + 1013904223u; in[i] = (int)((s >> 8) % (uint32_t)range); srt[i] = in[i]; }
+        std::nth_element(srt, srt + 12, srt + 25);
+        const int got = median25(in, vals::med5_sort5, vals::med5_merge, vals::med5_select);
+        if (got != srt[12]) { std::printf("random case %d differs: %d vs %d\n", it, got, srt[12]); return 1; }
+    }
+    std::puts("ok");
+    return 0;
+}
