@@ -901,13 +901,16 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void median3_kernel(const u
 // tests/test_median5_net.py on all 2^25 0-1 inputs) and is built so that neighbouring windows share most of it:
 //   A) every column's 5 vertical values are sorted once (a column belongs to 5 windows),
 //   B) the sorted columns (2i, 2i + 1) are merged into sorted 10-lists once (such a pair belongs to 4 windows),
-//   C) a window takes its two pairs and its fifth column: columns x-2 .. x+2 for even x are pairs (x-2, x-1), (x, x+1)
-//      and column x+2; for odd x they are column x-2 and pairs (x-1, x), (x+1, x+2).
+//   C) of two neighbouring pairs (four columns) the middle six of their 20 values are selected once: they belong to the
+//      window that adds the column on their right (even x: pairs (x-2, x-1), (x, x+1) and column x+2) and to the one that
+//      adds the column on their left (odd x: column x-2 and pairs (x-1, x), (x+1, x+2)),
+//   D) per window, the median is rank 5 of those six and its fifth sorted column.
 // On field pairs (byte p, byte p+2): E_d = bytes (4d, 4d+2) and O_d = bytes (4d+1, 4d+3) of dword d sort as two columns
 // each, merge(E_d, O_d) = P_d holds pairs (4d, 4d+1) | (4d+2, 4d+3), and the lists a window needs that straddle two dwords
-// are v_alignbit_b32 of neighbouring P (Q_d = P_d.hi | P_d+1.lo) or sorted columns.  Per 16 pixels: 12 column sorts,
-// 6 merges, 8 selections = 216 + 156 + 368 packed min / max and ~100 moves and shifts -- 53 per pixel, where the tile
-// kernel in ipx_rank.hip spends 2 x 120 on a from-scratch selection per pixel pair.
+// are v_alignbit_b32 of neighbouring registers (Q_d = P_d.hi | P_d+1.lo; M_d = middle(P_d, Q_d) serves the odd windows
+// of dword d as it is and the even ones as M_d-1.hi | M_d.lo).  Per 16 pixels: 12 column sorts, 6 merges, 5 middles,
+// 8 finals = 216 + 156 + 180 + 80 packed min / max, 114 v_alignbit and ~60 moves and v_perm -- 50 per pixel, where the
+// tile kernel in ipx_rank.hip spends 2 x 120 on a from-scratch selection per pixel pair.
 #define M5_T us2
 #define M5_MIN(a, b) __builtin_elementwise_min(a, b)
 #define M5_MAX(a, b) __builtin_elementwise_max(a, b)
@@ -976,7 +979,7 @@ __global__ __launch_bounds__(256) void median5_kernel(const uint8_t* __restrict_
             }
             settle(ring[K - 1], nx[u]);
             load_win<1, 2>(nx[u], row(t + PF), b0, g.L);
-            us2 sE[ND][5], sO[ND][5], P[ND][10], Q[ND - 1][10];
+            us2 sE[ND][5], sO[ND][5], P[ND][10], M[ND - 1][6];
             u32x4 ov;
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
@@ -988,20 +991,24 @@ __global__ __launch_bounds__(256) void median5_kernel(const uint8_t* __restrict_
                 med5_sort5(sE[d]);
                 med5_sort5(sO[d]);
                 med5_merge(sE[d], sO[d], P[d]);
-                if (d >= 1) {
+                if (d >= 1) {                                    // columns 4j .. 4j + 3 | 4j + 2 .. 4j + 5 of dword d - 1
+                    us2 Q[10];
 #pragma unroll
-                    for (int i = 0; i < 10; ++i) Q[d - 1][i] = hi_lo(P[d - 1][i], P[d][i]);
+                    for (int i = 0; i < 10; ++i) Q[i] = hi_lo(P[d - 1][i], P[d][i]);
+                    med5_middle(P[d - 1], Q, M[d - 1]);
                 }
                 if (d >= 2) {                                    // output dword e = d - 1 (window dword index; row bytes 4 (e - 1) ..)
                     const int e = d - 1;
-                    us2 ce[5], co[5];
+                    us2 ce[5], co[5], me[6];
 #pragma unroll
                     for (int r = 0; r < 5; ++r) {
                         ce[r] = hi_lo(sE[e][r], sE[e + 1][r]);   // columns 4j + 2 | 4j + 4 for the windows at 4j | 4j + 2
                         co[r] = hi_lo(sO[e - 1][r], sO[e][r]);   // columns 4j - 1 | 4j + 1 for the windows at 4j + 1 | 4j + 3
                     }
-                    const us2 oe = med5_select(Q[e - 1], P[e], ce);
-                    const us2 oo = med5_select(P[e], Q[e], co);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) me[r] = hi_lo(M[e - 1][r], M[e][r]);   // columns 4j - 2 .. 4j + 1 | 4j .. 4j + 3
+                    const us2 oe = med5_final(me, ce);
+                    const us2 oo = med5_final(M[e], co);
                     ov[e - 1] = pack_fields(oe, oo);
                 }
             }

@@ -6,11 +6,13 @@ neighbouring windows share:
   A) med5_sort5:  sort the 5 vertical values of a column (9 comparators; a column belongs to 5 windows),
   B) med5_merge:  Batcher odd-even merge of two adjacent sorted columns into a sorted 10-list (13 comparators; the kernel
                   only merges the pairs that start at an even column, each of which serves 4 windows),
-  C) med5_select: per window, the odd-even merge of two such 10-lists restricted to what its ranks 7..12 need, then
-                  rank 5 of those six and the window's fifth sorted column (7 of the 25 are known to lie below them).
+  C) med5_middle: ranks 7..12 of the union of two such 10-lists (the odd-even merge restricted to what they need; 7 of
+                  a window's 25 values are then known to lie below them and 7 above).  Four adjacent columns belong to
+                  two windows, the one that adds the column to their right and the one that adds the column to their left,
+  D) med5_final:  per window, rank 5 of those six and the window's fifth sorted column.
 The whole network is checked here on all 2^25 0-1 inputs (bit-parallel on Python integers; by the 0-1 principle a
 min / max network that selects the median of every 0-1 input selects it for every input), the unused halves of the
-comparators of C are dropped, and the three pieces are written as C++ over the macros M5_T / M5_MIN / M5_MAX, so that
+comparators of C and D are dropped, and the four pieces are written as C++ over the macros M5_T / M5_MIN / M5_MAX, so that
 tests/test_median5_net.py can run the EMITTED text through the same exhaustive check on the CPU (M5_T = uint64_t,
 and / or) before the kernel uses it on packed 16-bit pairs.
 
@@ -107,14 +109,17 @@ def pieces():
     merge_ces, merge_out = oddeven_merge(a, b)
     p, q, c = list(range(10)), list(range(10, 20)), list(range(20, 25))
     m20, o20 = oddeven_merge(p, q)
-    m11, o11 = oddeven_merge(o20[7:13], c)
-    sel = prune(m20 + m11, [o11[5]])
-    return (merge_ces, merge_out), (sel, o11[5])
+    mid = o20[7:13]
+    m11, o11 = oddeven_merge(mid, c)
+    fin = prune(m11, [o11[5]])
+    need = {k for i, j, _, _ in fin for k in (i, j)} & set(mid)           # what D reads of the six
+    return (merge_ces, merge_out), (prune(m20, sorted(need)), mid), (fin, o11[5])
 
 
-def verify(merge, select):
-    """The composed network (5 column sorts, 2 pair merges, the selection) on all 2^25 0-1 inputs."""
-    (merge_ces, merge_out), (sel, out) = merge, select
+def verify(merge, middle, final):
+    """The composed network (5 column sorts, 2 pair merges, the middle six, the final selection) on all 2^25 0-1 inputs."""
+    (merge_ces, merge_out), (mid_ces, mid), (fin, out) = merge, middle, final
+    sel = mid_ces + fin
     w = inputs01(25)                                           # wire 5 c + r = column c, row r
     for c in range(5):
         run([(5 * c + i, 5 * c + j) for i, j in SORT5], w)
@@ -140,12 +145,13 @@ def emit_ce(i, j, ni, nj, name):
     return f"    {b} = M5_MAX({a}, {b});"
 
 
-def emit(merge, select):
-    (merge_ces, merge_out), (sel, out) = merge, select
+def emit(merge, middle, final):
+    (merge_ces, merge_out), (mid_ces, mid), (fin, out) = merge, middle, final
+    nops = lambda ces: sum(int(a) + int(b) for _, _, a, b in ces)
     L = []
     L.append("// ipx_median5_net.inc -- GENERATED by scripts/gen_median5_net.py (which verifies it on all 2^25 0-1 inputs); do not edit.")
     L.append("// Needs M5_T (value type), M5_MIN(a, b), M5_MAX(a, b) and M5_FN (function qualifiers).")
-    L.append(f"// Operations: sort5 {2 * len(SORT5)}, merge {2 * len(merge_ces)}, select {sum(int(a) + int(b) for _, _, a, b in sel)} (min or max each).")
+    L.append(f"// Operations: sort5 {2 * len(SORT5)}, merge {2 * len(merge_ces)}, middle {nops(mid_ces)}, final {nops(fin)} (min or max each).")
     L.append("")
     L.append("// v[0] <= v[1] <= ... <= v[4] afterwards")
     L.append("M5_FN void med5_sort5(M5_T (&v)[5])")
@@ -164,13 +170,24 @@ def emit(merge, select):
         L.append(f"    p[{r}] = w{k};")
     L.append("}")
     L.append("")
-    L.append("// p, q sorted 10-lists and c a sorted column, 25 values in all -> their median (rank 12 from 0)")
-    L.append("M5_FN M5_T med5_select(const M5_T (&p)[10], const M5_T (&q)[10], const M5_T (&c)[5])")
+    L.append("// p, q sorted 10-lists -> m = ranks 7 .. 12 of the twenty, sorted")
+    L.append("M5_FN void med5_middle(const M5_T (&p)[10], const M5_T (&q)[10], M5_T (&m)[6])")
     L.append("{")
-    used = sorted({k for i, j, _, _ in sel for k in (i, j)})
-    src = lambda k: f"p[{k}]" if k < 10 else f"q[{k - 10}]" if k < 20 else f"c[{k - 20}]"
+    used = sorted({k for i, j, _, _ in mid_ces for k in (i, j)})
+    L.append("    M5_T " + ", ".join(f"w{k} = {'p' if k < 10 else 'q'}[{k % 10}]" for k in used) + ";")
+    for i, j, ni, nj in mid_ces:
+        L.append(emit_ce(i, j, ni, nj, lambda k: f"w{k}"))
+    for r, k in enumerate(mid):
+        L.append(f"    m[{r}] = w{k};")
+    L.append("}")
+    L.append("")
+    L.append("// m from med5_middle and c the window's fifth sorted column -> the median of the 25 (rank 12 from 0)")
+    L.append("M5_FN M5_T med5_final(const M5_T (&m)[6], const M5_T (&c)[5])")
+    L.append("{")
+    used = sorted({k for i, j, _, _ in fin for k in (i, j)})
+    src = lambda k: f"m[{mid.index(k)}]" if k in mid else f"c[{k - 20}]"
     L.append("    M5_T " + ", ".join(f"w{k} = {src(k)}" for k in used) + ";")
-    for i, j, ni, nj in sel:
+    for i, j, ni, nj in fin:
         L.append(emit_ce(i, j, ni, nj, lambda k: f"w{k}"))
     L.append(f"    return w{out};")
     L.append("}")
@@ -178,12 +195,12 @@ def emit(merge, select):
 
 
 if __name__ == "__main__":
-    merge, select = pieces()
-    ok = verify(merge, select)
+    merge, middle, final = pieces()
+    ok = verify(merge, middle, final)
     print("median of 25 on all 2^25 0-1 inputs:", "correct" if ok else "WRONG")
     if not ok:
         sys.exit(1)
-    text = emit(merge, select)
+    text = emit(merge, middle, final)
     print(text.split("\n")[2][3:])
     if "--check" in sys.argv:
         same = os.path.exists(OUT) and open(OUT).read() == text

@@ -1,6 +1,6 @@
 // Runs the EMITTED text of image-processing_amd/csrc/ipx_median5_net.inc on the CPU (test infrastructure, not product):
 //   1) all 2^25 0-1 inputs, 64 patterns per machine word (min = and, max = or), composed exactly as median5_kernel
-//      composes the pieces: five column sorts, two pair merges, the selection;
+//      composes the pieces: five column sorts, two pair merges, the middle six, the final selection;
 //   2) random byte windows (many ties) against std::nth_element.
 // Prints "ok" and exits 0, or says what failed.
 #include <algorithm>
@@ -27,18 +27,19 @@ namespace vals {
 #include "ipx_median5_net.inc"
 }
 
-template <typename T, typename S, typename M, typename Q>
-static T median25(const T (&in)[25], S sort5, M merge, Q select)
+template <typename T, typename S, typename M, typename D, typename F>
+static T median25(const T (&in)[25], S sort5, M merge, D middle, F final)
 {
     T col[5][5];
     for (int c = 0; c < 5; ++c) {
         for (int r = 0; r < 5; ++r) col[c][r] = in[5 * c + r];
         sort5(col[c]);
     }
-    T p[10], q[10];
+    T p[10], q[10], m[6];
     merge(col[0], col[1], p);
     merge(col[2], col[3], q);
-    return select(p, q, col[4]);
+    middle(p, q, m);
+    return final(m, col[4]);
 }
 
 int main()
@@ -54,7 +55,7 @@ int main()
         }
         // ones >= 13  <=>  bit 4 set, or bit 3 set and (bit 2 set and (bit 1 or bit 0))
         const uint64_t want = cnt[4] | (cnt[3] & cnt[2] & (cnt[1] | cnt[0]));
-        const uint64_t got = median25(in, bits::med5_sort5, bits::med5_merge, bits::med5_select);
+        const uint64_t got = median25(in, bits::med5_sort5, bits::med5_merge, bits::med5_middle, bits::med5_final);
         if (got != want) { std::printf("0-1 block %u differs: %016llx vs %016llx\n", blk, (unsigned long long)got, (unsigned long long)want); return 1; }
     }
     uint32_t s = 12345u;
@@ -64,7 +65,7 @@ int main()
         const int range = 1 + (int)((s >> 24) % 5u == 0 ? 3 : (s >> 16) & 255u);     // a fifth of the cases: values 0..3 (ties)
         for (int i = 0; i < 25; ++i) { s = s * 1664525u + 1013904223u; in[i] = (int)((s >> 8) % (uint32_t)range); srt[i] = in[i]; }
         std::nth_element(srt, srt + 12, srt + 25);
-        const int got = median25(in, vals::med5_sort5, vals::med5_merge, vals::med5_select);
+        const int got = median25(in, vals::med5_sort5, vals::med5_merge, vals::med5_middle, vals::med5_final);
         if (got != srt[12]) { std::printf("random case %d differs: %d vs %d\n", it, got, srt[12]); return 1; }
     }
     std::puts("ok");
