@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "ipx_fields.h"
+#include <type_traits>
 #include <atomic>
 
 extern "C" int ipx_lut_u8(void*, const uint8_t*, uint8_t*, int, int, int, int, int64_t, int64_t, int64_t, int64_t, const uint8_t*);
@@ -714,7 +715,11 @@ template <bool DILATE> __device__ __forceinline__ us2 mm(us2 a, us2 b)
     return DILATE ? __builtin_elementwise_max(a, b) : __builtin_elementwise_min(a, b);
 }
 
-template <bool DILATE, int R>
+// SHAPE names the two column masks at compile time where they are the usual ones (the generic form tests a mask bit per
+// tap and slot: 27 vector instructions per pixel for 5 x 5, VALU-bound): 1 = mask A is the centre column and mask B the
+// full row (OpenCV's 3 x 3 and 5 x 5 ellipses, crosses), 2 = mask A is the full row and there is no mask B (rectangles);
+// the full-row min / max of a lane's slot pairs p, p + 1 share the taps p - R + 1 .. p + R.  0 = any two masks.
+template <bool DILATE, int R, int SHAPE>
 __global__ __launch_bounds__(256) void morph_small_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                           ConvGeom g, MorphSE se)
 {
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(256) void morph_small_kernel(const uint8_t* __restr
     const uint8_t* simg = src + (int64_t)img * g.s_img;
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     const int nrows = y1 - y0;
-    const bool useB = se.mask[1] != 0;                           // wave-uniform
+    const bool useB = SHAPE == 1 || (SHAPE == 0 && se.mask[1] != 0);   // wave-uniform
 
     auto row_y = [&](int t) { return y0 - R + t; };              // source row of walk step t
     auto row_ptr_cl = [&](int t) {
@@ -755,6 +760,24 @@ __global__ __launch_bounds__(256) void morph_small_kernel(const uint8_t* __restr
         if (last) {
 #pragma unroll
             for (int i = 0; i < HD; ++i) W.w[HD + 4 + i] = NEU;
+        }
+        if (SHAPE != 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = 4 * k;                             // slots 2k, 2k + 1 = fields p, p + 1
+                us2 common = fld<1, R>(W, p - R + 1);
+#pragma unroll
+                for (int j = p - R + 2; j <= p + R; ++j) common = mm<DILATE>(common, fld<1, R>(W, j));
+                const us2 full0 = mm<DILATE>(common, fld<1, R>(W, p - R)), full1 = mm<DILATE>(common, fld<1, R>(W, p + R + 1));
+                if (SHAPE == 1) {
+                    fa[2 * k] = fld<1, R>(W, p); fa[2 * k + 1] = fld<1, R>(W, p + 1);
+                    fb[2 * k] = full0; fb[2 * k + 1] = full1;
+                } else {
+                    fa[2 * k] = full0; fa[2 * k + 1] = full1;
+                    fb[2 * k] = neu; fb[2 * k + 1] = neu;
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -800,7 +823,7 @@ __global__ __launch_bounds__(256) void morph_small_kernel(const uint8_t* __restr
                     if (se.sel[i] == 1) {
 #pragma unroll
                         for (int s = 0; s < 8; ++s) o[s] = mm<DILATE>(o[s], ha[rs][s]);
-                    } else if (se.sel[i] == 2) {
+                    } else if (SHAPE != 2 && se.sel[i] == 2) {
 #pragma unroll
                         for (int s = 0; s < 8; ++s) o[s] = mm<DILATE>(o[s], hb[rs][s]);
                     }
@@ -1320,13 +1343,23 @@ int ipx_morph_small(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int
     if (int rc = make_conv_geom("ipx_morph_u8", g, src, dst, n, h, w, 1, r, 4, 2 * r + 1, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
     if (g.nlanes == 0) return 0;                                 // rows too short for the vector lanes: the tile kernel
     const dim3 grid(conv_grid(g)), block(conv_block(g));
-    if (r == 1) {
-        if (dilate) hipLaunchKernelGGL((morph_small_kernel<true, 1>), grid, block, 0, st, src, dst, g, se);
-        else hipLaunchKernelGGL((morph_small_kernel<false, 1>), grid, block, 0, st, src, dst, g, se);
-    } else {
-        if (dilate) hipLaunchKernelGGL((morph_small_kernel<true, 2>), grid, block, 0, st, src, dst, g, se);
-        else hipLaunchKernelGGL((morph_small_kernel<false, 2>), grid, block, 0, st, src, dst, g, se);
-    }
+    const uint32_t full = (1u << se_rows) - 1u, centre = 1u << r;
+    int shape = nm == 2 && se.mask[0] == centre && se.mask[1] == full ? 1 : nm == 1 && se.mask[0] == full ? 2 : 0;
+#ifdef IPX_DEV
+    if (env_int("IPX_MORPH_GENERIC", 0)) shape = 0;
+#endif
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, 0, st, src, dst, g, se); };
+    auto pick = [&](auto D, auto RR) {
+        constexpr bool d = decltype(D)::value;
+        constexpr int rr = decltype(RR)::value;
+        if (shape == 1) go(morph_small_kernel<d, rr, 1>);
+        else if (shape == 2) go(morph_small_kernel<d, rr, 2>);
+        else go(morph_small_kernel<d, rr, 0>);
+    };
+    typedef std::integral_constant<int, 1> R1;
+    typedef std::integral_constant<int, 2> R2;
+    if (r == 1) { if (dilate) pick(std::true_type{}, R1{}); else pick(std::false_type{}, R1{}); }
+    else { if (dilate) pick(std::true_type{}, R2{}); else pick(std::false_type{}, R2{}); }
     if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of morph_small_kernel failed");
     return 1;
 }

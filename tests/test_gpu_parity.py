@@ -714,7 +714,10 @@ def test_morphology_small_elements_strip_walker(dev, shape):
     ses = [np.ones((3, 3), np.uint8), np.ones((5, 5), np.uint8), ops.ellipse_se(3), ops.ellipse_se(5),
            np.array([[1, 0, 0], [1, 1, 0], [1, 0, 0]], np.uint8), np.array([[0, 0, 0], [0, 1, 1], [0, 0, 0]], np.uint8),
            np.array([[0, 0, 1, 1, 0], [1, 0, 0, 0, 1], [0, 0, 0, 0, 0], [1, 0, 0, 0, 1], [0, 0, 1, 1, 0]], np.uint8),
-           np.array([[1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 1, 0, 0], [0, 1, 0, 0, 0], [1, 0, 0, 0, 0]], np.uint8)]
+           np.array([[1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 1, 0, 0], [0, 1, 0, 0, 0], [1, 0, 0, 0, 0]], np.uint8),
+           # centre column / full row (the specialised kernel form) with empty rows; the same two masks met in the other order
+           np.array([[0, 0, 1, 0, 0], [0, 0, 0, 0, 0], [1, 1, 1, 1, 1], [0, 0, 0, 0, 0], [0, 0, 1, 0, 0]], np.uint8),
+           np.array([[1, 1, 1], [0, 1, 0], [1, 1, 1]], np.uint8), np.array([[0, 0, 0], [1, 1, 1], [0, 0, 0]], np.uint8)]
     for se in ses:
         np.testing.assert_array_equal(host(ops.erode(t, se)), O.erode_u8(img, se), err_msg=f"erode {se.tolist()}")
         np.testing.assert_array_equal(host(ops.dilate(t, se)), O.dilate_u8(img, se), err_msg=f"dilate {se.tolist()}")
