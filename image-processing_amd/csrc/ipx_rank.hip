@@ -72,18 +72,22 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
 __device__ __forceinline__ us2 bins_lo(uint32_t d) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, d, 0x0c010c00u)); }
 __device__ __forceinline__ us2 bins_hi(uint32_t d) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, d, 0x0c030c02u)); }
 
-__device__ __forceinline__ int find_rank(us2 h01, us2 h23, int need)
+// The wave's window histogram (4 bins per lane) -> the bin where the running count first reaches `need`, written to
+// s_out[slot] by the one lane that holds it: that lane's inclusive prefix has reached `need` and its exclusive prefix
+// has not (lane 63's inclusive prefix is k*k, so there always is one).  Nothing goes through scalar registers
+// (ballot / s_ff1 / v_readlane made every output pixel a vector -> scalar -> vector round trip: 590 cycles per pixel and
+// wave where the instructions need 160), so the searches of consecutive pixels overlap.
+__device__ __forceinline__ void find_rank_store(us2 h01, us2 h23, int need, int lane, uint8_t* s_out, int slot)
 {
     const us2 ones = {1, 1};
     const int t = (int)__builtin_amdgcn_udot2(h01, ones, __builtin_amdgcn_udot2(h23, ones, 0u, false), false);
     const int p = wave_inclusive_scan(t);
-    const uint64_t reached = __ballot(p >= need);                    // never empty: lane 63 holds k*k
-    const int L = (int)__builtin_ctzll(reached);
-    const int below = __builtin_amdgcn_readlane(p - t, L);
-    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint32_t, h01), L);
-    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint32_t, h23), L);
+    const int below = p - t;
+    const uint32_t a = __builtin_bit_cast(uint32_t, h01), b = __builtin_bit_cast(uint32_t, h23);
     const int c0 = below + (int)(a & 0xffffu), c1 = c0 + (int)(a >> 16), c2 = c1 + (int)(b & 0xffffu);
-    return 4 * L + (c0 < need) + (c1 < need) + (c2 < need);
+    // every lane stores -- the others into a byte of their own behind the results -- so that there is no branch and the
+    // searches of consecutive pixels can be interleaved (the DPP steps of one fill the wait states of the other)
+    s_out[p >= need && below < need ? slot : kHsW + lane] = (uint8_t)(4 * lane + (c0 < need) + (c1 < need) + (c2 < need));
 }
 
 __global__ __launch_bounds__(64) void median_hist_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, RankGeom g, int band_rows)
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(64) void median_hist_kernel(const uint8_t* __restri
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     const int lane = (int)threadIdx.x;
     const int r = g.rx, K = 2 * r + 1, nc = kHsW + 2 * r, need = (K * K) / 2 + 1;
+    uint8_t* s_out = hb + nc * 256;                                 // the row's 64 results, then 64 bytes nobody reads
     const int y1 = y0 + band_rows < g.h ? y0 + band_rows : g.h;
     const int nout = g.w - x0 < kHsW ? g.w - x0 : kHsW;
 
@@ -140,19 +145,21 @@ __global__ __launch_bounds__(64) void median_hist_kernel(const uint8_t* __restri
             h01 += bins_lo(d);
             h23 += bins_hi(d);
         }
-        int res = find_rank(h01, h23, need);
+        find_rank_store(h01, h23, need, lane, s_out, 0);
         auto column = [&](int c) { c = c < nc ? c : nc - 1; return s_hist[c * 64 + ((lane + c) & 63)]; };
         uint32_t d_new = column(1 + 2 * r), d_old = column(0);
-        for (int i = 1; i < nout; ++i) {
+        // always 64 steps (the strip holds 64 + 2r column histograms whatever the image width -- columns past its right
+        // edge are replicas of the last one -- and results past the edge are not stored): a fixed trip count unrolls
+#pragma unroll 4
+        for (int i = 1; i < kHsW; ++i) {
             const uint32_t d_new2 = column(i + 1 + 2 * r), d_old2 = column(i);   // next step's, in flight during the search
             h01 = h01 + bins_lo(d_new) - bins_lo(d_old);
             h23 = h23 + bins_hi(d_new) - bins_hi(d_old);
-            const int m = find_rank(h01, h23, need);
-            res = lane == i ? m : res;
+            find_rank_store(h01, h23, need, lane, s_out, i);
             d_new = d_new2;
             d_old = d_old2;
         }
-        if (lane < nout) dimg[(int64_t)y * g.d_row + x0 + lane] = (uint8_t)res;
+        if (lane < nout) dimg[(int64_t)y * g.d_row + x0 + lane] = s_out[lane];   // (a wave's LDS accesses complete in order)
         __syncthreads();
         if (y + 1 < y1) {
 #pragma unroll
@@ -352,7 +359,7 @@ int ipx_median_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, in
     g.tiles_y = (h + band_rows - 1) / band_rows;
     const uint64_t nb = (uint64_t)n * g.tiles_x * g.tiles_y;
     if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many tiles", fn);
-    hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)nb), dim3(64), (size_t)(kHsW + k - 1) * 256, (hipStream_t)stream, src, dst, g, band_rows);
+    hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)nb), dim3(64), (size_t)(kHsW + k - 1) * 256 + 2 * kHsW, (hipStream_t)stream, src, dst, g, band_rows);
     IPX_LAUNCH_CHECK("median_hist_kernel");
     return IPX_OK;
 }
