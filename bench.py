@@ -303,6 +303,7 @@ def main():
                 ("dilate_5", "morph_small_kernel<true,2>", 2, lambda: ops.dilate(gray, ops.ellipse_se(5))),
                 ("median_3", "median3_kernel", 2, lambda: ops.median_blur(gray, 3)),
                 ("median_5", "median5_kernel", 2, lambda: ops.median_blur(gray, 5)),
+                ("median_7", "median7_kernel", 2, lambda: ops.median_blur(gray, 7)),
                 ("median_31", "median_hist_kernel", 2, lambda: ops.median_blur(gray, 31)),
             ]:
                 kernels[name] = row(kern, bpp, time_op(fn), "20 back-to-back launches between two HIP events")

@@ -1040,6 +1040,121 @@ __global__ __launch_bounds__(256) void median5_kernel(const uint8_t* __restrict_
     }
 }
 
+// ---- 7 x 7 median on the strip walker: the same idea one level up ------------------------------------------------------
+// (scripts/gen_median7_net.py: every piece verified on all sorted 0-1 inputs.)  A window is three column pairs and one
+// more column: columns sorted once (7 windows share a column), even-start pairs merged once (P_d = pairs (4j, 4j+1) |
+// (4j+2, 4j+3) of dword d), the two pairs of a dword merged into a 28-list once (Q_d; two dwords per packed operation:
+// P_d.lo | P_d+1.lo against P_d.hi | P_d+1.hi), and of a quad with the pair on its left | on its right the middle eight of
+// the 42 once per two windows: T_d = mid8(Q_d | Q_d, P_d-1.hi | P_d+1.lo).  The windows at 4j | 4j+2 then add the columns
+// 4j-3 | 4j-1 (the sorted O field of dword d-1 as it is) and those at 4j+1 | 4j+3 the columns 4j+4 | 4j+6 (the sorted E
+// field of dword d+1).  Per 16 pixels 12 sorts, 6 merges, 2 quads, 4 mid8, 8 finals = 384 + 252 + 220 + 288 + 112 packed
+// min / max and ~250 v_perm / v_alignbit: 94 per pixel, where the per-pixel selection of ipx_rank.hip takes ~400.
+#define M7_T us2
+#define M7_MIN(a, b) __builtin_elementwise_min(a, b)
+#define M7_MAX(a, b) __builtin_elementwise_max(a, b)
+#define M7_FN __device__ __forceinline__
+#include "ipx_median7_net.inc"
+#undef M7_T
+#undef M7_MIN
+#undef M7_MAX
+#undef M7_FN
+
+__device__ __forceinline__ us2 perm2(us2 hi_src, us2 lo_src, uint32_t sel)
+{
+    return __builtin_bit_cast(us2, __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi_src), __builtin_bit_cast(uint32_t, lo_src), sel));
+}
+
+template <int PF>
+__global__ __launch_bounds__(256) void median7_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, ConvGeom g)
+{
+    constexpr int K = 7, ND = 6;                                 // dwords d = 0 .. 5 of the window: row bytes b0 - 4 .. b0 + 19
+    typedef Win<1, 3> WR;
+    static_assert(WR::ND == ND, "one halo dword on either side");
+    unsigned img; int y0, y1, lane0;
+    if (!wave_item(g, img, y0, y1, lane0)) return;
+    const int gl = lane0 + (int)(threadIdx.x & 63u);
+    if (gl >= g.nlanes) return;
+    const int b0 = lane_b0(g, gl);
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    const int nrows = y1 - y0;
+    auto row = [&](int t) {                                      // walk step t = source row y0 - 3 + t, replicated at the ends
+        int yy = y0 - 3 + t;
+        yy = yy < 0 ? 0 : yy > g.h - 1 ? g.h - 1 : yy;
+        return simg + (int64_t)yy * g.s_row;
+    };
+    auto even = [](uint32_t w) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c020c00u)); };   // bytes (0, 2)
+    auto odd = [](uint32_t w) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c030c01u)); };    // bytes (1, 3)
+    uint32_t ring[K][ND];                                        // the last 7 source rows, raw (84 field registers would not fit)
+    auto settle = [&](uint32_t (&o)[ND], WR& W) {
+        if (first) W.w[0] = (W.w[1] & 255u) * 0x01010101u;       // bytes -4 .. -1 = byte 0
+        if (last) W.w[5] = (W.w[4] >> 24) * 0x01010101u;         // bytes 16 .. 19 = byte 15
+#pragma unroll
+        for (int d = 0; d < ND; ++d) o[d] = W.w[d];
+    };
+    {
+        WR w0[K - 1];
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) load_win<1, 3>(w0[j], row(j), b0, g.L);
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) settle(ring[j + 1], w0[j]);
+    }
+    WR nx[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) load_win<1, 3>(nx[j], row(K - 1 + j), b0, g.L);
+    for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = t0 + u, yo = t - (K - 1);
+            if (yo >= nrows) break;                              // wave-uniform
+#pragma unroll
+            for (int r = 0; r < K - 1; ++r) {
+#pragma unroll
+                for (int d = 0; d < ND; ++d) ring[r][d] = ring[r + 1][d];
+            }
+            settle(ring[K - 1], nx[u]);
+            load_win<1, 3>(nx[u], row(t + PF), b0, g.L);
+            us2 sE[ND][7], sO[ND][7], P[ND][14];
+            auto pairs = [&](int d) {                            // sorted E / O fields and their merge for dword d
+#pragma unroll
+                for (int r = 0; r < K; ++r) { sE[d][r] = even(ring[r][d]); sO[d][r] = odd(ring[r][d]); }
+                med7_sort7(sE[d]);
+                med7_sort7(sO[d]);
+                med7_merge(sE[d], sO[d], P[d]);
+            };
+            u32x4 ov;
+            auto outputs = [&](int e) {                          // output dwords e, e + 1 (window dword indices; e = 1 or 3)
+                us2 A[14], B[14], QQ[28];
+#pragma unroll
+                for (int i = 0; i < 14; ++i) {
+                    A[i] = perm2(P[e + 1][i], P[e][i], 0x05040100u);     // P_e.lo | P_e+1.lo
+                    B[i] = perm2(P[e + 1][i], P[e][i], 0x07060302u);     // P_e.hi | P_e+1.hi
+                }
+                med7_quad(A, B, QQ);                                     // Q_e | Q_e+1
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int d = e + h;
+                    us2 Qd[28], third[14], T[8];
+#pragma unroll
+                    for (int i = 0; i < 28; ++i) Qd[i] = perm2(QQ[i], QQ[i], h ? 0x03020302u : 0x01000100u);
+#pragma unroll
+                    for (int i = 0; i < 14; ++i) third[i] = hi_lo(P[d - 1][i], P[d + 1][i]);
+                    med7_mid8(Qd, third, T);
+                    const us2 oe = med7_final(T, sO[d - 1]);             // windows 4j | 4j + 2 add columns 4j - 3 | 4j - 1
+                    const us2 oo = med7_final(T, sE[d + 1]);             // windows 4j + 1 | 4j + 3 add columns 4j + 4 | 4j + 6
+                    ov[d - 1] = pack_fields(oe, oo);
+                }
+            };
+            pairs(0); pairs(1); pairs(2); pairs(3);
+            outputs(1);
+            pairs(4); pairs(5);
+            outputs(3);
+            st16_nt(dimg + (int64_t)(y0 + yo) * g.d_row + b0, ov);
+        }
+    }
+}
+
 // ---- generic two-pass path (any odd K <= IPX_MAX_GAUSS_K) -----------------------------------------------
 struct TapsBig { uint16_t k[IPX_MAX_GAUSS_K + 1]; };
 
@@ -1387,6 +1502,19 @@ int ipx_median5_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, 
     if (g.nlanes == 0) return 0;
     hipLaunchKernelGGL(median5_kernel<PF>, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
     if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median5_kernel failed");
+    return 1;
+}
+
+// Called by ipx_median_blur_u8 for k = 7, same contract.
+int ipx_median7_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                       int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img)
+{
+    constexpr int PF = 2;
+    ConvGeom g;
+    if (int rc = make_conv_geom("ipx_median_blur_u8", g, src, dst, n, h, w, 1, 3, 4, PF, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
+    if (g.nlanes == 0) return 0;
+    hipLaunchKernelGGL(median7_kernel<PF>, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
+    if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median7_kernel failed");
     return 1;
 }
 

@@ -1,4 +1,4 @@
-// Runs the EMITTED text of image-processing_amd/csrc/ipx_median5_net.inc on the CPU (test infrastructure, not product):
+// Runs the EMITTED text of image-processing_amd/csrc/ipx_median5_net.inc (and ipx_median7_net.inc, below) on the CPU (test infrastructure, not product):
 //   1) all 2^25 0-1 inputs, 64 patterns per machine word (min = and, max = or), composed exactly as median5_kernel
 //      composes the pieces: five column sorts, two pair merges, the middle six, the final selection;
 //   2) random byte windows (many ties) against std::nth_element.
@@ -42,8 +42,82 @@ static T median25(const T (&in)[25], S sort5, M merge, D middle, F final)
     return final(m, col[4]);
 }
 
+// ---- 7 x 7: image-processing_amd/csrc/ipx_median7_net.inc (2^49 inputs cannot be enumerated: the generator proves every piece
+// on all sorted 0-1 inputs; here the emitted text runs on 2^26 random 0-1 patterns and on random byte windows) ----------
+namespace bits7 {
+#define M7_T uint64_t
+#define M7_MIN(a, b) ((a) & (b))
+#define M7_MAX(a, b) ((a) | (b))
+#define M7_FN static inline
+#include "ipx_median7_net.inc"
+#undef M7_T
+#undef M7_MIN
+#undef M7_MAX
+#undef M7_FN
+}
+namespace vals7 {
+#define M7_T int
+#define M7_MIN(a, b) std::min(a, b)
+#define M7_MAX(a, b) std::max(a, b)
+#define M7_FN static inline
+#include "ipx_median7_net.inc"
+}
+
+// quad_first: the window's quad is its first two pairs and the third pair follows (else the pair comes first); the seventh
+// column is the last one either way (the kernel's even and odd windows are mirror images of each other)
+template <typename T, typename S, typename M, typename Q, typename D, typename F>
+static T median49(const T (&in)[49], bool quad_first, S sort7, M merge, Q quad, D mid8, F final)
+{
+    T col[7][7];
+    for (int c = 0; c < 7; ++c) {
+        for (int r = 0; r < 7; ++r) col[c][r] = in[7 * c + r];
+        sort7(col[c]);
+    }
+    T p[3][14], q[28], t[8];
+    for (int i = 0; i < 3; ++i) merge(col[2 * i], col[2 * i + 1], p[i]);
+    if (quad_first) { quad(p[0], p[1], q); mid8(q, p[2], t); }
+    else { quad(p[1], p[2], q); mid8(q, p[0], t); }
+    return final(t, col[6]);
+}
+
+static int check7()
+{
+    uint64_t s = 0x9e3779b97f4a7c15ull;
+    auto next = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (uint32_t blk = 0; blk < (1u << 20); ++blk) {
+        uint64_t in[49], cnt[6] = {0, 0, 0, 0, 0, 0};
+        // densities around one half, where the median flips: each wire is an AND / OR mix of random words
+        for (int i = 0; i < 49; ++i) {
+            const uint64_t a = next(), b = next(), c = next();
+            in[i] = (blk & 3u) == 0 ? a : (blk & 3u) == 1 ? (a & b) | c : (blk & 3u) == 2 ? (a | b) & c : a ^ (b & c);
+            uint64_t carry = in[i];
+            for (int b2 = 0; b2 < 6; ++b2) { const uint64_t t2 = cnt[b2] & carry; cnt[b2] ^= carry; carry = t2; }
+        }
+        // ones >= 25 = 011001b: bit 5, or bit 4 and (bit 3 and (bit 2 or bit 1 or bit 0 ... >= 1))
+        const uint64_t ge25 = cnt[5] | (cnt[4] & cnt[3] & (cnt[2] | cnt[1] | cnt[0]));
+        for (int qf = 0; qf < 2; ++qf) {
+            const uint64_t got = median49(in, qf != 0, bits7::med7_sort7, bits7::med7_merge, bits7::med7_quad, bits7::med7_mid8, bits7::med7_final);
+            if (got != ge25) { std::printf("7x7: 0-1 block %u differs\n", blk); return 1; }
+        }
+    }
+    uint32_t r = 777u;
+    for (int it = 0; it < 1000000; ++it) {
+        int in[49], srt[49];
+        r = r * 1664525u + 1013904223u;
+        const int range = 1 + (int)((r >> 24) % 5u == 0 ? 3 : (r >> 16) & 255u);
+        for (int i = 0; i < 49; ++i) { r = r * 1664525u + 1013904223u; in[i] = (int)((r >> 8) % (uint32_t)range); srt[i] = in[i]; }
+        std::nth_element(srt, srt + 24, srt + 49);
+        for (int qf = 0; qf < 2; ++qf) {
+            const int got = median49(in, qf != 0, vals7::med7_sort7, vals7::med7_merge, vals7::med7_quad, vals7::med7_mid8, vals7::med7_final);
+            if (got != srt[24]) { std::printf("7x7: random case %d differs: %d vs %d\n", it, got, srt[24]); return 1; }
+        }
+    }
+    return 0;
+}
+
 int main()
 {
+    if (check7()) return 1;
     static const uint64_t low[6] = {0xaaaaaaaaaaaaaaaaull, 0xccccccccccccccccull, 0xf0f0f0f0f0f0f0f0ull,
                                     0xff00ff00ff00ff00ull, 0xffff0000ffff0000ull, 0xffffffff00000000ull};
     for (uint32_t blk = 0; blk < (1u << 19); ++blk) {
