@@ -304,6 +304,7 @@ def main():
                 ("median_3", "median3_kernel", 2, lambda: ops.median_blur(gray, 3)),
                 ("median_5", "median5_kernel", 2, lambda: ops.median_blur(gray, 5)),
                 ("median_7", "median7_kernel", 2, lambda: ops.median_blur(gray, 7)),
+                ("median_9", "median9_kernel", 2, lambda: ops.median_blur(gray, 9)),
                 ("median_31", "median_hist_kernel", 2, lambda: ops.median_blur(gray, 31)),
             ]:
                 kernels[name] = row(kern, bpp, time_op(fn), "20 back-to-back launches between two HIP events")

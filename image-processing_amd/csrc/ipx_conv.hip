@@ -1155,6 +1155,112 @@ __global__ __launch_bounds__(256) void median7_kernel(const uint8_t* __restrict_
     }
 }
 
+// ---- 9 x 9 median on the strip walker -----------------------------------------------------------------------------------
+// (scripts/gen_median9_net.py.)  A window is four column pairs and one more column.  With P_d = the merged pairs
+// (4j, 4j+1) | (4j+2, 4j+3) of dword d, ONE packed quad merge per dword gives both alignments of neighbouring pairs,
+//   QR_d = quad(P_d, P_d.hi | P_d+1.lo) = quad(pairs 2d, 2d+1) | quad(pairs 2d+1, 2d+2),
+// and one packed selection per dword the middle ten of both alignments of neighbouring quads,
+//   OO_d = mid10(QR_d-1, QR_d) = columns 4j-4 .. 4j+3 | columns 4j-2 .. 4j+5,
+// each of which serves the window that adds the column on its left and the one that adds the column on its right: the
+// windows at 4j | 4j+2 are OO_d with the sorted E field of dword d+1 (columns 4j+4 | 4j+6) and those at 4j+1 | 4j+3 are
+// OO_d.hi | OO_d+1.lo with the sorted O field of dword d-1 (columns 4j-3 | 4j-1).  No byte shuffles beyond 148 v_alignbit per
+// 16 pixels; 12 sorts, 6 merges, 6 quads, 5 mid10, 8 finals = 600 + 360 + 924 + 600 + 144 packed min / max: 164 per pixel.
+#define M9_T us2
+#define M9_MIN(a, b) __builtin_elementwise_min(a, b)
+#define M9_MAX(a, b) __builtin_elementwise_max(a, b)
+#define M9_FN __device__ __forceinline__
+#include "ipx_median9_net.inc"
+#undef M9_T
+#undef M9_MIN
+#undef M9_MAX
+#undef M9_FN
+
+template <int PF>
+__global__ __launch_bounds__(256) void median9_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, ConvGeom g)
+{
+    constexpr int K = 9, ND = 6;                                 // dwords d = 0 .. 5 of the window: row bytes b0 - 4 .. b0 + 19
+    typedef Win<1, 4> WR;
+    static_assert(WR::ND == ND, "one halo dword on either side");
+    unsigned img; int y0, y1, lane0;
+    if (!wave_item(g, img, y0, y1, lane0)) return;
+    const int gl = lane0 + (int)(threadIdx.x & 63u);
+    if (gl >= g.nlanes) return;
+    const int b0 = lane_b0(g, gl);
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    const int nrows = y1 - y0;
+    auto row = [&](int t) {                                      // walk step t = source row y0 - 4 + t, replicated at the ends
+        int yy = y0 - 4 + t;
+        yy = yy < 0 ? 0 : yy > g.h - 1 ? g.h - 1 : yy;
+        return simg + (int64_t)yy * g.s_row;
+    };
+    auto even = [](uint32_t w) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c020c00u)); };   // bytes (0, 2)
+    auto odd = [](uint32_t w) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c030c01u)); };    // bytes (1, 3)
+    uint32_t ring[K][ND];                                        // the last 9 source rows, raw
+    auto settle = [&](uint32_t (&o)[ND], WR& W) {
+        if (first) W.w[0] = (W.w[1] & 255u) * 0x01010101u;       // bytes -4 .. -1 = byte 0
+        if (last) W.w[5] = (W.w[4] >> 24) * 0x01010101u;         // bytes 16 .. 19 = byte 15
+#pragma unroll
+        for (int d = 0; d < ND; ++d) o[d] = W.w[d];
+    };
+    {
+        WR w0[K - 1];
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) load_win<1, 4>(w0[j], row(j), b0, g.L);
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) settle(ring[j + 1], w0[j]);
+    }
+    WR nx[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) load_win<1, 4>(nx[j], row(K - 1 + j), b0, g.L);
+    for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = t0 + u, yo = t - (K - 1);
+            if (yo >= nrows) break;                              // wave-uniform
+#pragma unroll
+            for (int r = 0; r < K - 1; ++r) {
+#pragma unroll
+                for (int d = 0; d < ND; ++d) ring[r][d] = ring[r + 1][d];
+            }
+            settle(ring[K - 1], nx[u]);
+            load_win<1, 4>(nx[u], row(t + PF), b0, g.L);
+            us2 sE[ND][9], sO[ND][9], P[ND][18], QR[ND][36], OO[ND][10];
+            auto pairs = [&](int d) {
+#pragma unroll
+                for (int r = 0; r < K; ++r) { sE[d][r] = even(ring[r][d]); sO[d][r] = odd(ring[r][d]); }
+                med9_sort9(sE[d]);
+                med9_sort9(sO[d]);
+                med9_merge(sE[d], sO[d], P[d]);
+            };
+            auto quad = [&](int d) {                             // (P_5 has no right neighbour: QR_5's high half is never used)
+                us2 X[18];
+#pragma unroll
+                for (int i = 0; i < 18; ++i) X[i] = hi_lo(P[d][i], P[d + 1 < ND ? d + 1 : d][i]);
+                med9_quad(P[d], X, QR[d]);
+            };
+            auto octet = [&](int d) { med9_mid10(QR[d - 1], QR[d], OO[d]); };
+            u32x4 ov;
+            auto out = [&](int d) {
+                us2 T[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) T[i] = hi_lo(OO[d][i], OO[d + 1][i]);
+                const us2 oe = med9_final(OO[d], sE[d + 1]);     // windows 4j | 4j + 2 add columns 4j + 4 | 4j + 6
+                const us2 oo = med9_final(T, sO[d - 1]);         // windows 4j + 1 | 4j + 3 add columns 4j - 3 | 4j - 1
+                ov[d - 1] = pack_fields(oe, oo);
+            };
+            pairs(0); pairs(1); quad(0);
+            pairs(2); quad(1); octet(1);
+            pairs(3); quad(2); octet(2); out(1);
+            pairs(4); quad(3); octet(3); out(2);
+            pairs(5); quad(4); octet(4); out(3);
+            quad(5); octet(5); out(4);
+            st16_nt(dimg + (int64_t)(y0 + yo) * g.d_row + b0, ov);
+        }
+    }
+}
+
 // ---- generic two-pass path (any odd K <= IPX_MAX_GAUSS_K) -----------------------------------------------
 struct TapsBig { uint16_t k[IPX_MAX_GAUSS_K + 1]; };
 
@@ -1509,12 +1615,25 @@ int ipx_median5_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, 
 int ipx_median7_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
                        int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img)
 {
-    constexpr int PF = 2;
+    constexpr int PF = 2;                                        // rows in flight (1: 618 against 568 us)
     ConvGeom g;
     if (int rc = make_conv_geom("ipx_median_blur_u8", g, src, dst, n, h, w, 1, 3, 4, PF, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
     if (g.nlanes == 0) return 0;
     hipLaunchKernelGGL(median7_kernel<PF>, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
     if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median7_kernel failed");
+    return 1;
+}
+
+// Called by ipx_median_blur_u8 for k = 9, same contract.
+int ipx_median9_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                       int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img)
+{
+    constexpr int PF = 1;                                        // 2 rows in flight double the 25 KB loop body: 1243 against 1127 us
+    ConvGeom g;
+    if (int rc = make_conv_geom("ipx_median_blur_u8", g, src, dst, n, h, w, 1, 4, 4, PF, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
+    if (g.nlanes == 0) return 0;
+    hipLaunchKernelGGL(median9_kernel<PF>, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
+    if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median9_kernel failed");
     return 1;
 }
 

@@ -1,8 +1,10 @@
-"""The min / max networks of the 5 x 5 and 7 x 7 median kernels: the committed ipx_median5_net.inc is what the generator emits, and
+"""The min / max networks of the 5 x 5, 7 x 7 and 9 x 9 median kernels: the committed ipx_median5_net.inc is what the generator emits, and
 the emitted text selects the median (all 2^25 0-1 inputs and random byte windows, run on the CPU by tests/tools/median5_net_check.cpp)."""
 import os
 import subprocess
 import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -13,8 +15,9 @@ def test_committed_network_is_the_generated_one():
     assert "correct" in r.stdout and "up to date" in r.stdout
 
 
-def test_committed_7x7_network_is_the_generated_one():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_median7_net.py"), "--check"], capture_output=True, text=True, timeout=300)
+@pytest.mark.parametrize("k", [7, 9])
+def test_committed_larger_networks_are_the_generated_ones(k):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", f"gen_median{k}_net.py"), "--check"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "correct" in r.stdout and "up to date" in r.stdout
 

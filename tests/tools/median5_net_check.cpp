@@ -1,4 +1,4 @@
-// Runs the EMITTED text of image-processing_amd/csrc/ipx_median5_net.inc (and ipx_median7_net.inc, below) on the CPU (test infrastructure, not product):
+// Runs the EMITTED text of image-processing_amd/csrc/ipx_median5_net.inc (and ipx_median7_net.inc / ipx_median9_net.inc, below) on the CPU (test infrastructure, not product):
 //   1) all 2^25 0-1 inputs, 64 patterns per machine word (min = and, max = or), composed exactly as median5_kernel
 //      composes the pieces: five column sorts, two pair merges, the middle six, the final selection;
 //   2) random byte windows (many ties) against std::nth_element.
@@ -115,9 +115,75 @@ static int check7()
     return 0;
 }
 
+// ---- 9 x 9: image-processing_amd/csrc/ipx_median9_net.inc, composed as median9_kernel composes it ---------------------------
+namespace bits9 {
+#define M9_T uint64_t
+#define M9_MIN(a, b) ((a) & (b))
+#define M9_MAX(a, b) ((a) | (b))
+#define M9_FN static inline
+#include "ipx_median9_net.inc"
+#undef M9_T
+#undef M9_MIN
+#undef M9_MAX
+#undef M9_FN
+}
+namespace vals9 {
+#define M9_T int
+#define M9_MIN(a, b) std::min(a, b)
+#define M9_MAX(a, b) std::max(a, b)
+#define M9_FN static inline
+#include "ipx_median9_net.inc"
+}
+
+template <typename T, typename S, typename M, typename Q, typename D, typename F>
+static T median81(const T (&in)[81], S sort9, M merge, Q quad, D mid10, F final)
+{
+    T col[9][9];
+    for (int c = 0; c < 9; ++c) {
+        for (int r = 0; r < 9; ++r) col[c][r] = in[9 * c + r];
+        sort9(col[c]);
+    }
+    T p[4][18], q[2][36], t[10];
+    for (int i = 0; i < 4; ++i) merge(col[2 * i], col[2 * i + 1], p[i]);
+    quad(p[0], p[1], q[0]);
+    quad(p[2], p[3], q[1]);
+    mid10(q[0], q[1], t);
+    return final(t, col[8]);
+}
+
+static int check9()
+{
+    uint64_t s = 0x2545f4914f6cdd1dull;
+    auto next = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+    for (uint32_t blk = 0; blk < (1u << 19); ++blk) {
+        uint64_t in[81], cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 81; ++i) {
+            const uint64_t a = next(), b = next(), c = next();
+            in[i] = (blk & 3u) == 0 ? a : (blk & 3u) == 1 ? (a & b) | c : (blk & 3u) == 2 ? (a | b) & c : a ^ (b & c);
+            uint64_t carry = in[i];
+            for (int b2 = 0; b2 < 7; ++b2) { const uint64_t t2 = cnt[b2] & carry; cnt[b2] ^= carry; carry = t2; }
+        }
+        // ones >= 41 = 0101001b: bit 6, or bit 5 and (bit 4, or bit 3 and (bit 2 or bit 1 or bit 0))
+        const uint64_t ge41 = cnt[6] | (cnt[5] & (cnt[4] | (cnt[3] & (cnt[2] | cnt[1] | cnt[0]))));
+        const uint64_t got = median81(in, bits9::med9_sort9, bits9::med9_merge, bits9::med9_quad, bits9::med9_mid10, bits9::med9_final);
+        if (got != ge41) { std::printf("9x9: 0-1 block %u differs\n", blk); return 1; }
+    }
+    uint32_t r = 999u;
+    for (int it = 0; it < 500000; ++it) {
+        int in[81], srt[81];
+        r = r * 1664525u + 1013904223u;
+        const int range = 1 + (int)((r >> 24) % 5u == 0 ? 3 : (r >> 16) & 255u);
+        for (int i = 0; i < 81; ++i) { r = r * 1664525u + 1013904223u; in[i] = (int)((r >> 8) % (uint32_t)range); srt[i] = in[i]; }
+        std::nth_element(srt, srt + 40, srt + 81);
+        const int got = median81(in, vals9::med9_sort9, vals9::med9_merge, vals9::med9_quad, vals9::med9_mid10, vals9::med9_final);
+        if (got != srt[40]) { std::printf("9x9: random case %d differs: %d vs %d\n", it, got, srt[40]); return 1; }
+    }
+    return 0;
+}
+
 int main()
 {
-    if (check7()) return 1;
+    if (check7() || check9()) return 1;
     static const uint64_t low[6] = {0xaaaaaaaaaaaaaaaaull, 0xccccccccccccccccull, 0xf0f0f0f0f0f0f0f0ull,
                                     0xff00ff00ff00ff00ull, 0xffff0000ffff0000ull, 0xffffffff00000000ull};
     for (uint32_t blk = 0; blk < (1u << 19); ++blk) {
