@@ -1585,6 +1585,26 @@ int ipx_morph_small(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int
     return 1;
 }
 
+// The median walkers are bound by the vector pipe, not by memory, and the larger ones hold few waves per SIMD: on a small
+// batch (one 4K frame = 4 strips) the default 24- to 48-row segments leave most SIMDs without a wave.  Choose the segment
+// length that minimises rounds of resident waves x rows walked per wave (its rows + the K - 1 rows above them).
+static void median_segments(ConvGeom& g, int n, int K, int waves_per_simd, int gran)
+{
+    if (g.nstrips == 0) return;
+    const int64_t slots = 1024 * (int64_t)waves_per_simd, strips = (int64_t)n * g.nstrips;
+    if (strips * g.nsegs >= 2 * slots) return;                    // enough waves for the defaults
+    int best = g.seg_rows;
+    int64_t best_cost = INT64_MAX;
+    for (int seg = gran; seg <= g.seg_rows; seg += gran) {
+        const int64_t waves = strips * ((g.h + seg - 1) / seg);
+        const int64_t cost = ((waves + slots - 1) / slots) * (seg + K - 1);
+        if (cost < best_cost) { best_cost = cost; best = seg; }
+    }
+    g.seg_rows = best;
+    g.nsegs = (g.h + best - 1) / best;
+    g.main_blocks = (unsigned)((uint64_t)n * g.nsegs * g.blocks_per_seg);
+}
+
 // Called by ipx_median_blur_u8 (ipx_rank.hip) for k = 3: returns 1 if the strip walker launched, 0 if rows are too short
 // for its vector lanes (the tile kernel takes them), < 0 on error.
 int ipx_median3_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
@@ -1606,6 +1626,7 @@ int ipx_median5_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, 
     ConvGeom g;
     if (int rc = make_conv_geom("ipx_median_blur_u8", g, src, dst, n, h, w, 1, 2, 4, PF, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
     if (g.nlanes == 0) return 0;
+    median_segments(g, n, 5, 3, PF);
     hipLaunchKernelGGL(median5_kernel<PF>, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
     if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median5_kernel failed");
     return 1;
@@ -1619,6 +1640,7 @@ int ipx_median7_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, 
     ConvGeom g;
     if (int rc = make_conv_geom("ipx_median_blur_u8", g, src, dst, n, h, w, 1, 3, 4, PF, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
     if (g.nlanes == 0) return 0;
+    median_segments(g, n, 7, 2, PF);
     hipLaunchKernelGGL(median7_kernel<PF>, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
     if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median7_kernel failed");
     return 1;
@@ -1632,6 +1654,7 @@ int ipx_median9_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, 
     ConvGeom g;
     if (int rc = make_conv_geom("ipx_median_blur_u8", g, src, dst, n, h, w, 1, 4, 4, PF, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
     if (g.nlanes == 0) return 0;
+    median_segments(g, n, 9, 1, PF);
     hipLaunchKernelGGL(median9_kernel<PF>, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
     if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median9_kernel failed");
     return 1;

@@ -81,17 +81,23 @@ __device__ __forceinline__ us2 bins_hi(uint32_t d) { return __builtin_bit_cast(u
 // has not (lane 63's inclusive prefix is k*k, so there always is one).  Nothing goes through scalar registers
 // (ballot / s_ff1 / v_readlane made every output pixel a vector -> scalar -> vector round trip: 590 cycles per pixel and
 // wave where the instructions need 160), so the searches of consecutive pixels overlap.
-__device__ __forceinline__ void find_rank_store(us2 h01, us2 h23, int need, int lane, uint8_t* s_out, int slot)
+// Two pixels per search: the lane totals of both window histograms share one register (16 bits each: k*k <= 961, so the
+// low half never carries into the high one) and ONE wave prefix sum serves both.
+__device__ __forceinline__ void find_rank_store2(us2 a01, us2 a23, us2 b01, us2 b23, int need, int lane, uint8_t* s_out, int slot_a, int slot_b)
 {
     const us2 ones = {1, 1};
-    const int t = (int)__builtin_amdgcn_udot2(h01, ones, __builtin_amdgcn_udot2(h23, ones, 0u, false), false);
-    const int p = wave_inclusive_scan(t);
-    const int below = p - t;
-    const uint32_t a = __builtin_bit_cast(uint32_t, h01), b = __builtin_bit_cast(uint32_t, h23);
-    const int c0 = below + (int)(a & 0xffffu), c1 = c0 + (int)(a >> 16), c2 = c1 + (int)(b & 0xffffu);
-    // every lane stores -- the others into a byte of their own behind the results -- so that there is no branch and the
-    // searches of consecutive pixels can be interleaved (the DPP steps of one fill the wait states of the other)
-    s_out[p >= need && below < need ? slot : kHsW + lane] = (uint8_t)(4 * lane + (c0 < need) + (c1 < need) + (c2 < need));
+    const uint32_t ta = __builtin_amdgcn_udot2(a01, ones, __builtin_amdgcn_udot2(a23, ones, 0u, false), false);
+    const uint32_t tb = __builtin_amdgcn_udot2(b01, ones, __builtin_amdgcn_udot2(b23, ones, 0u, false), false);
+    const uint32_t p = (uint32_t)wave_inclusive_scan((int)(ta | (tb << 16)));
+    // every lane stores -- the others into bytes of their own behind the results -- so that there is no branch
+    auto resolve = [&](uint32_t pp, uint32_t t, us2 h01, us2 h23, int slot, int spare) {
+        const int below = (int)(pp - t);
+        const uint32_t a = __builtin_bit_cast(uint32_t, h01), b = __builtin_bit_cast(uint32_t, h23);
+        const int c0 = below + (int)(a & 0xffffu), c1 = c0 + (int)(a >> 16), c2 = c1 + (int)(b & 0xffffu);
+        s_out[(int)pp >= need && below < need ? slot : spare] = (uint8_t)(4 * lane + (c0 < need) + (c1 < need) + (c2 < need));
+    };
+    resolve(p & 0xffffu, ta, a01, a23, slot_a, kHsW + lane);
+    resolve(p >> 16, tb, b01, b23, slot_b, 2 * kHsW + lane);
 }
 
 __global__ __launch_bounds__(64) void median_hist_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, RankGeom g, int band_rows)
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(64) void median_hist_kernel(const uint8_t* __restri
     uint8_t* dimg = dst + (int64_t)img * g.d_img;
     const int lane = (int)threadIdx.x;
     const int r = g.rx, K = 2 * r + 1, nc = kHsW + 2 * r, need = (K * K) / 2 + 1;
-    uint8_t* s_out = hb + nc * 256;                                 // the row's 64 results, then 64 bytes nobody reads
+    uint8_t* s_out = hb + nc * 256;                                 // the row's 64 results, then 128 bytes nobody reads
     const int y1 = y0 + band_rows < g.h ? y0 + band_rows : g.h;
     const int nout = g.w - x0 < kHsW ? g.w - x0 : kHsW;
 
@@ -143,25 +149,32 @@ __global__ __launch_bounds__(64) void median_hist_kernel(const uint8_t* __restri
 #pragma unroll
             for (int q = 0; q < 2; ++q) { ov[q] = simg[ro + xc[q]]; nv[q] = simg[rn + xc[q]]; }
         }
-        us2 h01 = {0, 0}, h23 = {0, 0};
-        for (int c = 0; c < K; ++c) {
-            const uint32_t d = s_hist[c * 64 + ((lane + c) & 63)];
-            h01 += bins_lo(d);
-            h23 += bins_hi(d);
-        }
-        find_rank_store(h01, h23, need, lane, s_out, 0);
+        // two streams per wave, output columns 0 .. 31 and 32 .. 63, in lockstep: their instructions interleave (one
+        // stream alone left the wave stalled for half of its 390 cycles per pixel) and share the prefix sum
+        constexpr int HW = kHsW / 2;
+        us2 a01 = {0, 0}, a23 = {0, 0}, b01 = {0, 0}, b23 = {0, 0};
         auto column = [&](int c) { c = c < nc ? c : nc - 1; return s_hist[c * 64 + ((lane + c) & 63)]; };
-        uint32_t d_new = column(1 + 2 * r), d_old = column(0);
-        // always 64 steps (the strip holds 64 + 2r column histograms whatever the image width -- columns past its right
+        for (int c = 0; c < K; ++c) {
+            const uint32_t da = column(c), db = column(HW + c);
+            a01 += bins_lo(da);
+            a23 += bins_hi(da);
+            b01 += bins_lo(db);
+            b23 += bins_hi(db);
+        }
+        find_rank_store2(a01, a23, b01, b23, need, lane, s_out, 0, HW);
+        uint32_t an = column(1 + 2 * r), ao = column(0), bn = column(HW + 1 + 2 * r), bo = column(HW);
+        // always 32 steps (the strip holds 64 + 2r column histograms whatever the image width -- columns past its right
         // edge are replicas of the last one -- and results past the edge are not stored): a fixed trip count unrolls
 #pragma unroll 4
-        for (int i = 1; i < kHsW; ++i) {
-            const uint32_t d_new2 = column(i + 1 + 2 * r), d_old2 = column(i);   // next step's, in flight during the search
-            h01 = h01 + bins_lo(d_new) - bins_lo(d_old);
-            h23 = h23 + bins_hi(d_new) - bins_hi(d_old);
-            find_rank_store(h01, h23, need, lane, s_out, i);
-            d_new = d_new2;
-            d_old = d_old2;
+        for (int i = 1; i < HW; ++i) {
+            const uint32_t an2 = column(i + 1 + 2 * r), ao2 = column(i);          // next step's, in flight during the search
+            const uint32_t bn2 = column(HW + i + 1 + 2 * r), bo2 = column(HW + i);
+            a01 = a01 + bins_lo(an) - bins_lo(ao);
+            a23 = a23 + bins_hi(an) - bins_hi(ao);
+            b01 = b01 + bins_lo(bn) - bins_lo(bo);
+            b23 = b23 + bins_hi(bn) - bins_hi(bo);
+            find_rank_store2(a01, a23, b01, b23, need, lane, s_out, i, HW + i);
+            an = an2; ao = ao2; bn = bn2; bo = bo2;
         }
         if (lane < nout) dimg[(int64_t)y * g.d_row + x0 + lane] = s_out[lane];   // (a wave's LDS accesses complete in order)
         __syncthreads();
@@ -371,7 +384,7 @@ int ipx_median_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, in
     g.tiles_y = (h + band_rows - 1) / band_rows;
     const uint64_t nb = (uint64_t)n * g.tiles_x * g.tiles_y;
     if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many tiles", fn);
-    hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)nb), dim3(64), (size_t)(kHsW + k - 1) * 256 + 2 * kHsW, (hipStream_t)stream, src, dst, g, band_rows);
+    hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)nb), dim3(64), (size_t)(kHsW + k - 1) * 256 + 3 * kHsW, (hipStream_t)stream, src, dst, g, band_rows);
     IPX_LAUNCH_CHECK("median_hist_kernel");
     return IPX_OK;
 }
