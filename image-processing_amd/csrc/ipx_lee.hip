@@ -358,6 +358,21 @@ extern "C" int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst,
         if (segs > (h + 63) / 64) segs = (h + 63) / 64;
         if (segs < 1) segs = 1;
         sg.seg_rows = (h + segs - 1) / segs;
+        {   // small batches (one 4K frame: 270 blocks for 768 to 2048 block slots): the segment length that minimises rounds of
+            // resident blocks x rows a block works through (its rows, the K - 1 rows above them, ~4 rows' worth of table)
+            const int K = 2 * kk + 1, extra = K - 1 + (kk <= 2 ? 4 : 0);
+            const int64_t slots = 256 * (kk == 1 ? 8 : 3), per_seg = (int64_t)n * sg.blocks_per_seg;
+            if (per_seg * ((h + sg.seg_rows - 1) / sg.seg_rows) < 2 * slots) {
+                int64_t best_cost = INT64_MAX;
+                int best = sg.seg_rows;
+                for (int seg = K; seg <= sg.seg_rows; seg += K) {
+                    const int64_t blocks = per_seg * ((h + seg - 1) / seg);
+                    const int64_t cost = ((blocks + slots - 1) / slots) * (seg + extra);
+                    if (cost < best_cost) { best_cost = cost; best = seg; }
+                }
+                sg.seg_rows = best;
+            }
+        }
         sg.nsegs = (h + sg.seg_rows - 1) / sg.seg_rows;
         const uint64_t nb = (uint64_t)n * sg.nsegs * sg.blocks_per_seg;
         if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many blocks", fn);
