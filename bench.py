@@ -298,6 +298,7 @@ def main():
                 ("lee_w3", "lee_small_kernel<3>", 2, lambda: ops.lee_filter(gray, 3)),
                 ("lee_w5", "lee_small_kernel<5>", 2, lambda: ops.lee_filter(gray, 5)),
                 ("lee_w7", "lee_small_kernel<7>", 2, lambda: ops.lee_filter(gray, 7)),
+                ("lee_w9", "lee_small_kernel<9>", 2, lambda: ops.lee_filter(gray, 9)),
                 ("lee_w31", "lee_kernel", 2, lambda: ops.lee_filter(gray, 31)),
                 ("erode_3", "morph_small_kernel<false,1>", 2, lambda: ops.erode(gray, ops.ellipse_se(3))),
                 ("dilate_5", "morph_small_kernel<true,2>", 2, lambda: ops.dilate(gray, ops.ellipse_se(5))),

@@ -191,7 +191,7 @@ struct LeeSmallGeom {
 template <int K>
 __global__ __launch_bounds__(256) void lee_small_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, LeeSmallGeom g)
 {
-    constexpr int k = K / 2, n = K * K, NT = 255 * n + 1, LB = K <= 3 ? 4 : 8;   // LB: bytes per row load (>= K + 1)
+    constexpr int k = K / 2, n = K * K, NT = 255 * n + 1, LB = K <= 3 ? 4 : K <= 7 ? 8 : 12;   // LB: bytes per row load (>= K + 1)
     constexpr bool TABLE = K <= 5;                         // K = 7: the table would take 100 KB of LDS; mean and q are computed
     extern __shared__ float s_tab[];                       // mean[S] = s_tab[S], q[S] = s_tab[NT + S]
     const float fn = (float)n, cn = rn_div(1.0f, fn);
@@ -221,6 +221,9 @@ __global__ __launch_bounds__(256) void lee_small_kernel(const uint8_t* __restric
     // window byte j (column x - k + j) is byte j + d of the load, d = x - k - a (negative in the row's first lane): byte
     // selectors for v_perm_b32, 0x0c = constant zero for bytes the load does not hold (never used by an interior pixel)
     const int d = x - k - a;
+    // (LB = 12: three dwords are more than one v_perm_b32 can select from; there the window bytes come from the load by a
+    // per-lane byte shift, v_alignbyte_b32 over [0, w0, w1, w2, 0], the dword part of the shift chosen by compares)
+    const uint32_t shb = (uint32_t)(d + 4) & 3u, shd = (uint32_t)(d + 4) >> 2;     // 0 <= d + 4 <= LB - 1 - k + 4 = 11
     uint32_t sel[LB / 4];
 #pragma unroll
     for (int q = 0; q < LB / 4; ++q) {
@@ -249,7 +252,15 @@ __global__ __launch_bounds__(256) void lee_small_kernel(const uint8_t* __restric
         float fl[K + 1];
 #pragma unroll
         for (int q = 0; q < LB / 4; ++q) {
-            const uint32_t wv = __builtin_amdgcn_perm(LB == 8 ? v.w[LB / 4 - 1] : 0u, v.w[0], sel[q]);
+            uint32_t wv;
+            if (LB <= 8) {
+                wv = __builtin_amdgcn_perm(LB == 8 ? v.w[LB / 4 - 1] : 0u, v.w[0], sel[q]);
+            } else {
+                const uint32_t e[7] = {0u, v.w[0], v.w[LB >= 8 ? 1 : 0], v.w[LB >= 12 ? 2 : 0], 0u, 0u, 0u};
+                const uint32_t c0 = __builtin_amdgcn_alignbyte(e[q + 1], e[q], shb), c1 = __builtin_amdgcn_alignbyte(e[q + 2], e[q + 1], shb),
+                               c2 = __builtin_amdgcn_alignbyte(e[q + 3], e[q + 2], shb);
+                wv = shd == 0 ? c0 : shd == 1 ? c1 : c2;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (4 * q + j <= K) fl[4 * q + j] = (float)((wv >> (8 * j)) & 255u);
@@ -347,7 +358,7 @@ extern "C" int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst,
     if (window_size < 1 || window_size / 2 > kMaxK)
         return ipx_fail(IPX_ERR_INVALID, "%s: window_size=%d must be in 1..%d", fn, window_size, 2 * kMaxK + 1);
     const int kk = window_size / 2;                        // server.py:717
-    if (kk >= 1 && kk <= 3 && w >= 64) {                   // 3 x 3, 5 x 5, 7 x 7: the column walker
+    if (kk >= 1 && kk <= 4 && w >= 64) {                   // 3 x 3 ... 9 x 9: the column walker
         LeeSmallGeom sg;
         sg.h = h; sg.w = w;
         sg.s_row = src_row_stride; sg.s_img = src_img_stride; sg.d_row = dst_row_stride; sg.d_img = dst_img_stride;
@@ -361,7 +372,7 @@ extern "C" int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst,
         {   // small batches (one 4K frame: 270 blocks for 768 to 2048 block slots): the segment length that minimises rounds of
             // resident blocks x rows a block works through (its rows, the K - 1 rows above them, ~4 rows' worth of table)
             const int K = 2 * kk + 1, extra = K - 1 + (kk <= 2 ? 4 : 0);
-            const int64_t slots = 256 * (kk == 1 ? 8 : 3), per_seg = (int64_t)n * sg.blocks_per_seg;
+            const int64_t slots = 256 * (kk == 1 ? 8 : kk <= 3 ? 3 : 1), per_seg = (int64_t)n * sg.blocks_per_seg;
             if (per_seg * ((h + sg.seg_rows - 1) / sg.seg_rows) < 2 * slots) {
                 int64_t best_cost = INT64_MAX;
                 int best = sg.seg_rows;
@@ -379,7 +390,8 @@ extern "C" int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst,
         const size_t lds = kk <= 2 ? (size_t)(255 * (2 * kk + 1) * (2 * kk + 1) + 1) * 2 * sizeof(float) : 0;
         if (kk == 1) hipLaunchKernelGGL(lee_small_kernel<3>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
         else if (kk == 2) hipLaunchKernelGGL(lee_small_kernel<5>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
-        else hipLaunchKernelGGL(lee_small_kernel<7>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
+        else if (kk == 3) hipLaunchKernelGGL(lee_small_kernel<7>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
+        else hipLaunchKernelGGL(lee_small_kernel<9>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
         IPX_LAUNCH_CHECK("lee_small_kernel");
         return IPX_OK;
     }
