@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void lee_small_kernel(const uint8_t* __restric
     // selectors for v_perm_b32, 0x0c = constant zero for bytes the load does not hold (never used by an interior pixel)
     const int d = x - k - a;
     // (LB = 12: three dwords are more than one v_perm_b32 can select from; there the window bytes come from the load by a
-    // per-lane byte shift, v_alignbyte_b32 over [0, w0, w1, w2, 0], the dword part of the shift chosen by compares)
-    const uint32_t shb = (uint32_t)(d + 4) & 3u, shd = (uint32_t)(d + 4) >> 2;     // 0 <= d + 4 <= LB - 1 - k + 4 = 11
+    // per-lane byte shift, v_alignbyte_b32 over [0, 0, w0, w1, w2, 0, 0], the dword part of the shift chosen by compares)
+    const uint32_t shb = (uint32_t)(d + 8) & 3u, shd = (uint32_t)(d + 8) >> 2;     // 3 <= d + 8 <= LB - 1 - k + 8 <= 15
     uint32_t sel[LB / 4];
 #pragma unroll
     for (int q = 0; q < LB / 4; ++q) {
@@ -256,10 +256,10 @@ __global__ __launch_bounds__(256) void lee_small_kernel(const uint8_t* __restric
             if (LB <= 8) {
                 wv = __builtin_amdgcn_perm(LB == 8 ? v.w[LB / 4 - 1] : 0u, v.w[0], sel[q]);
             } else {
-                const uint32_t e[7] = {0u, v.w[0], v.w[LB >= 8 ? 1 : 0], v.w[LB >= 12 ? 2 : 0], 0u, 0u, 0u};
+                const uint32_t e[9] = {0u, 0u, v.w[0], v.w[LB >= 8 ? 1 : 0], v.w[LB >= 12 ? 2 : 0], 0u, 0u, 0u, 0u};
                 const uint32_t c0 = __builtin_amdgcn_alignbyte(e[q + 1], e[q], shb), c1 = __builtin_amdgcn_alignbyte(e[q + 2], e[q + 1], shb),
-                               c2 = __builtin_amdgcn_alignbyte(e[q + 3], e[q + 2], shb);
-                wv = shd == 0 ? c0 : shd == 1 ? c1 : c2;
+                               c2 = __builtin_amdgcn_alignbyte(e[q + 3], e[q + 2], shb), c3 = __builtin_amdgcn_alignbyte(e[q + 4], e[q + 3], shb);
+                wv = shd == 0 ? c0 : shd == 1 ? c1 : shd == 2 ? c2 : c3;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -358,7 +358,7 @@ extern "C" int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst,
     if (window_size < 1 || window_size / 2 > kMaxK)
         return ipx_fail(IPX_ERR_INVALID, "%s: window_size=%d must be in 1..%d", fn, window_size, 2 * kMaxK + 1);
     const int kk = window_size / 2;                        // server.py:717
-    if (kk >= 1 && kk <= 4 && w >= 64) {                   // 3 x 3 ... 9 x 9: the column walker
+    if (kk >= 1 && kk <= 5 && w >= 64) {                   // 3 x 3 ... 11 x 11: the column walker
         LeeSmallGeom sg;
         sg.h = h; sg.w = w;
         sg.s_row = src_row_stride; sg.s_img = src_img_stride; sg.d_row = dst_row_stride; sg.d_img = dst_img_stride;
@@ -391,7 +391,8 @@ extern "C" int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst,
         if (kk == 1) hipLaunchKernelGGL(lee_small_kernel<3>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
         else if (kk == 2) hipLaunchKernelGGL(lee_small_kernel<5>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
         else if (kk == 3) hipLaunchKernelGGL(lee_small_kernel<7>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
-        else hipLaunchKernelGGL(lee_small_kernel<9>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
+        else if (kk == 4) hipLaunchKernelGGL(lee_small_kernel<9>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
+        else hipLaunchKernelGGL(lee_small_kernel<11>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, src, dst, sg);
         IPX_LAUNCH_CHECK("lee_small_kernel");
         return IPX_OK;
     }

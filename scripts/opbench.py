@@ -57,7 +57,7 @@ def main():
             s = time_op(lambda: ops.gaussian_blur(b8, k), reps=3)
             print(f"gauss{k}_8k_bgr {s*1e6:9.1f} us {p8*6/s/1e9:8.1f} GB/s", flush=True)
     if "lee" in what:
-        for wnd in (3, 5, 9, 15, 31):
+        for wnd in (3, 5, 9, 11, 15, 31):
             g1 = gray[:1]
             s = time_op(lambda: ops.lee_filter(g1, wnd), reps=5)
             print(f"lee w={wnd:2d} one 4K gray frame {s*1e6:9.1f} us  {H*W/s/1e6:9.1f} MP/s", flush=True)

@@ -464,12 +464,12 @@ def test_lee_filter_golden_and_batch(dev, golden):
 
 
 def test_lee_column_walker(dev):
-    """windows 3, 4 (= 5), 5, 6 (= 7), 7, 8 (= 9) and 9 on images at least 64 columns wide run on the column walker (lee_small_kernel): widths around
+    """windows 3, 4 (= 5), 5, ... 10 (= 11) and 11 on images at least 64 columns wide run on the column walker (lee_small_kernel): widths around
     the 64-column strips and 256-column blocks, heights around the row segments, flat patches (var == 0), two-level and
     near-constant images (tiny variances), a strided batch with an unaligned base; every pixel equal to numpy's result."""
     rng = np.random.default_rng(91)
     for h, w in ((1, 64), (2, 65), (3, 64), (5, 66), (6, 127), (64, 128), (65, 129), (130, 257), (200, 300), (7, 1031)):
-        for wnd in (3, 4, 5, 6, 7, 8, 9):
+        for wnd in (3, 4, 5, 6, 7, 8, 9, 10, 11):
             img = np.clip(rng.normal(120, 40, (h, w)), 0, 255).astype(np.uint8)
             if h > 12:
                 img[3:12, 4:40] = 61
@@ -477,11 +477,11 @@ def test_lee_column_walker(dev):
     for img in (np.where(rng.random((90, 200)) < 0.5, 0, 255).astype(np.uint8),
                 (100 + (rng.random((90, 200)) < 0.02)).astype(np.uint8), np.zeros((20, 70), np.uint8), np.full((20, 70), 255, np.uint8),
                 rng.integers(0, 256, (300, 333), dtype=np.uint8)):
-        for wnd in (3, 5, 7, 9):
+        for wnd in (3, 5, 7, 9, 11):
             np.testing.assert_array_equal(host(ops.lee_filter(dev_t(img, dev), wnd)), O.lee_filter_u8(img, wnd))
     big = rng.integers(0, 256, (3, 70, 400), dtype=np.uint8)
     view = dev_t(big, dev)[:, 5:65, 3:3 + 311].unsqueeze(-1)
-    for wnd in (3, 5, 7, 9):
+    for wnd in (3, 5, 7, 9, 11):
         got = host(ops.lee_filter(view, wnd))
         for i in range(3):
             np.testing.assert_array_equal(got[i, :, :, 0], O.lee_filter_u8(np.ascontiguousarray(big[i, 5:65, 3:314]), wnd))

@@ -252,7 +252,7 @@ def test_gauss_taps_are_far_from_rounding_ties_for_every_k():
 
 
 def test_markstein_division_by_window_size(tmp_path):
-    """ipx_lee.hip divides the variance sum by n = 9 / 25 / 49 / 81 with y = fl(a c), r = fma(-n, y, a), q = fma(r, c, y), c = fl(1 / n).
+    """ipx_lee.hip divides the variance sum by n = 9 / 25 / 49 / 81 / 121 with y = fl(a c), r = fma(-n, y, a), q = fma(r, c, y), c = fl(1 / n).
     The three steps scale exactly with powers of two, so correct rounding for all 2^23 significands of three binades (and a
     strided sample of fifty more) is correct rounding for every float whose quotient is normal.  Plain C, gcc, no GPU."""
     import shutil, subprocess
@@ -265,9 +265,9 @@ def test_markstein_division_by_window_size(tmp_path):
 #include <string.h>
 #include <math.h>
 int main(void) {
-    const int ns[] = {9, 25, 49, 81};
+    const int ns[] = {9, 25, 49, 81, 121};
     long bad = 0;
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < 5; ++ni) {
         const float n = (float)ns[ni], c = 1.0f / n;
         for (int e = 90; e <= 150; ++e) {
             const uint32_t step = (e >= 126 && e <= 128) ? 1u : 4099u;

@@ -121,7 +121,7 @@ while time.time() < t_end:
         fails += check(f"gauss{k}", ops.gaussian_blur(t, k), per_image(lambda x: O.gaussian_blur_u8(x, k), img), (n, h, w, c, strided))
     elif op == "lee":
         h, w = min(h, 120), min(w, 300)
-        win = int(rng.choice([1, 2, 3, 3, 4, 5, 5, 7, 9, 15, 31]))
+        win = int(rng.choice([1, 2, 3, 3, 4, 5, 5, 7, 9, 9, 10, 11, 11, 15, 31]))
         t, img = make(n, h, w, 1, strided)
         fails += check(f"lee{win}", ops.lee_filter(t, win), per_image(lambda x: O.lee_filter_u8(x, win), img), (n, h, w, strided))
     elif op == "median":
