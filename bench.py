@@ -306,6 +306,7 @@ def main():
                 ("median_5", "median5_kernel", 2, lambda: ops.median_blur(gray, 5)),
                 ("median_7", "median7_kernel", 2, lambda: ops.median_blur(gray, 7)),
                 ("median_9", "median9_kernel", 2, lambda: ops.median_blur(gray, 9)),
+                ("median_11", "median11_kernel", 2, lambda: ops.median_blur(gray, 11)),
                 ("median_31", "median_hist_kernel", 2, lambda: ops.median_blur(gray, 31)),
             ]:
                 kernels[name] = row(kern, bpp, time_op(fn), "20 back-to-back launches between two HIP events")

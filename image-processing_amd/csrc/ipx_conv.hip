@@ -1261,6 +1261,112 @@ __global__ __launch_bounds__(256) void median9_kernel(const uint8_t* __restrict_
     }
 }
 
+// ---- 11 x 11 median on the strip walker ---------------------------------------------------------------------------------
+// (scripts/gen_median11_net.py.)  Five column pairs and one more column; the packed forms line up as for 9 x 9:
+//   QR_d = quad(P_d, P_d.hi | P_d+1.lo),   U_d = mid12(QR_d-1, QR_d, P_d+1) = columns 4j-4 .. 4j+5 | columns 4j-2 .. 4j+7,
+// the windows at 4j | 4j+2 add columns 4j-5 | 4j-3 (O_d-2.hi | O_d-1.lo) and those at 4j+1 | 4j+3 columns 4j+6 | 4j+8
+// (E_d+1.hi | E_d+2.lo).  Two halo dwords on either side.  5238 packed min / max per 16 pixels; the working set (two 44-lists
+// and a 22-list in flight above a ring of 11 x 8 dwords) lives in VGPRs and AGPRs, one wave per SIMD.
+#define M11_T us2
+#define M11_MIN(a, b) __builtin_elementwise_min(a, b)
+#define M11_MAX(a, b) __builtin_elementwise_max(a, b)
+#define M11_FN __device__ __forceinline__
+#include "ipx_median11_net.inc"
+#undef M11_T
+#undef M11_MIN
+#undef M11_MAX
+#undef M11_FN
+
+__global__ __launch_bounds__(256) void median11_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, ConvGeom g)
+{
+    constexpr int K = 11, ND = 8;                                // dwords D = 0 .. 7 of the window: row bytes b0 - 8 .. b0 + 23
+    typedef Win<1, 5> WR;
+    static_assert(WR::ND == ND, "two halo dwords on either side");
+    unsigned img; int y0, y1, lane0;
+    if (!wave_item(g, img, y0, y1, lane0)) return;
+    const int gl = lane0 + (int)(threadIdx.x & 63u);
+    if (gl >= g.nlanes) return;
+    const int b0 = lane_b0(g, gl);
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    const int nrows = y1 - y0;
+    auto row = [&](int t) {                                      // walk step t = source row y0 - 5 + t, replicated at the ends
+        int yy = y0 - 5 + t;
+        yy = yy < 0 ? 0 : yy > g.h - 1 ? g.h - 1 : yy;
+        return simg + (int64_t)yy * g.s_row;
+    };
+    auto even = [](uint32_t w) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c020c00u)); };   // bytes (0, 2)
+    auto odd = [](uint32_t w) { return __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, w, 0x0c030c01u)); };    // bytes (1, 3)
+    uint32_t ring[K][ND];                                        // the last 11 source rows, raw
+    auto settle = [&](uint32_t (&o)[ND], WR& W) {
+        if (first) W.w[0] = W.w[1] = (W.w[2] & 255u) * 0x01010101u;      // bytes -8 .. -1 = byte 0
+        if (last) W.w[6] = W.w[7] = (W.w[5] >> 24) * 0x01010101u;        // bytes 16 .. 23 = byte 15
+#pragma unroll
+        for (int d = 0; d < ND; ++d) o[d] = W.w[d];
+    };
+    {
+#pragma unroll
+        for (int j = 0; j < K - 1; ++j) {
+            WR w0;
+            load_win<1, 5>(w0, row(j), b0, g.L);
+            settle(ring[j + 1], w0);
+        }
+    }
+    WR nx;
+    load_win<1, 5>(nx, row(K - 1), b0, g.L);
+    for (int t = K - 1; t - (K - 1) < nrows; ++t) {
+        const int yo = t - (K - 1);
+#pragma unroll
+        for (int r = 0; r < K - 1; ++r) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d) ring[r][d] = ring[r + 1][d];
+        }
+        settle(ring[K - 1], nx);
+        load_win<1, 5>(nx, row(t + 1), b0, g.L);
+        us2 sE[ND][11], sO[ND][11], P[ND][22], QR[ND][44], U[ND][12];
+        auto sortE = [&](int d) {
+            us2 v[11];
+#pragma unroll
+            for (int r = 0; r < K; ++r) v[r] = even(ring[r][d]);
+            med11_sort11(v, sE[d]);
+        };
+        auto sortO = [&](int d) {
+            us2 v[11];
+#pragma unroll
+            for (int r = 0; r < K; ++r) v[r] = odd(ring[r][d]);
+            med11_sort11(v, sO[d]);
+        };
+        auto pairs = [&](int d) { sortE(d); sortO(d); med11_merge(sE[d], sO[d], P[d]); };
+        auto quad = [&](int d) {
+            us2 X[22];
+#pragma unroll
+            for (int i = 0; i < 22; ++i) X[i] = hi_lo(P[d][i], P[d + 1][i]);
+            med11_quad(P[d], X, QR[d]);
+        };
+        u32x4 ov;
+        auto out = [&](int d) {                                  // output dword d = 2 .. 5 (row bytes 4 (d - 2) ..)
+            med11_mid12(QR[d - 1], QR[d], P[d + 1], U[d]);
+            us2 ce[11], co[11];
+#pragma unroll
+            for (int r = 0; r < 11; ++r) {
+                ce[r] = hi_lo(sO[d - 2][r], sO[d - 1][r]);       // columns 4j - 5 | 4j - 3 for the windows at 4j | 4j + 2
+                co[r] = hi_lo(sE[d + 1][r], sE[d + 2][r]);       // columns 4j + 6 | 4j + 8 for the windows at 4j + 1 | 4j + 3
+            }
+            ov[d - 2] = pack_fields(med11_final(U[d], ce), med11_final(U[d], co));
+        };
+        sortO(0);
+        pairs(1); pairs(2); quad(1);
+        pairs(3); quad(2);
+        pairs(4);
+        out(2);
+        quad(3); pairs(5); out(3);
+        quad(4); pairs(6); out(4);
+        quad(5); sortE(7); out(5);
+        st16_nt(dimg + (int64_t)(y0 + yo) * g.d_row + b0, ov);
+    }
+}
+
 // ---- generic two-pass path (any odd K <= IPX_MAX_GAUSS_K) -----------------------------------------------
 struct TapsBig { uint16_t k[IPX_MAX_GAUSS_K + 1]; };
 
@@ -1657,6 +1763,19 @@ int ipx_median9_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, 
     median_segments(g, n, 9, 1, PF);
     hipLaunchKernelGGL(median9_kernel<PF>, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
     if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median9_kernel failed");
+    return 1;
+}
+
+// Called by ipx_median_blur_u8 for k = 11, same contract.
+int ipx_median11_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                        int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img)
+{
+    ConvGeom g;
+    if (int rc = make_conv_geom("ipx_median_blur_u8", g, src, dst, n, h, w, 1, 5, 4, 1, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
+    if (g.nlanes == 0) return 0;
+    median_segments(g, n, 11, 1, 1);
+    hipLaunchKernelGGL(median11_kernel, dim3(conv_grid(g)), dim3(conv_block(g)), 0, st, src, dst, g);
+    if (hipGetLastError() != hipSuccess) return ipx_fail(IPX_ERR_HIP, "launch of median11_kernel failed");
     return 1;
 }
 

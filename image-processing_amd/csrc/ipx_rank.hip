@@ -20,6 +20,8 @@ int ipx_median7_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, 
                        int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img);
 int ipx_median9_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
                        int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img);
+int ipx_median11_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                        int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img);
 int ipx_morph_small(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
                     int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, int dilate,
                     const uint32_t* row_bits, int se_rows, int se_cols);
@@ -354,6 +356,10 @@ int ipx_median_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, in
     }
     if (k == 9) {
         const int rc = ipx_median9_walker((hipStream_t)stream, src, dst, n, h, w, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride);
+        if (rc != 0) return rc < 0 ? rc : IPX_OK;
+    }
+    if (k == 11) {
+        const int rc = ipx_median11_walker((hipStream_t)stream, src, dst, n, h, w, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride);
         if (rc != 0) return rc < 0 ? rc : IPX_OK;
     }
     if (k <= 9) {                                                 // register selection network, 2 pixels per thread

@@ -18,6 +18,6 @@ dev = torch.device("cuda:0")
 for n, h, w in ((24, 2160, 3840), (128, 1080, 1920)):
     g = torch.randint(0, 256, (n, h, w, 1), dtype=torch.uint8, device=dev)
     for _ in range(30): ops.median_blur(g, 3)
-    for k in (3, 5, 7, 9):
+    for k in (3, 5, 7, 9, 11, 13):
         us = time_op(lambda: ops.median_blur(g, k))
         print(f"{n} x {w}x{h} median k={k}: {us:8.1f} us  {2 * n * h * w / us / 1e3:7.1f} GB/s algorithmic", flush=True)

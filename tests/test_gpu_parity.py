@@ -511,9 +511,9 @@ def test_median_extremes_and_batch(dev):
         np.testing.assert_array_equal(got[i, :, :, 0], O.median_blur_u8(batch[i, :, :, 0], 5))
 
 
-@pytest.mark.parametrize("k", [3, 5, 7, 9])
+@pytest.mark.parametrize("k", [3, 5, 7, 9, 11])
 def test_median_strip_walkers(dev, k):
-    """k = 3, 5, 7 and 9 on rows long enough for the strip walkers (sorted columns; shared pair / quad merges from k = 5): widths
+    """k = 3, 5, 7, 9 and 11 on rows long enough for the strip walkers (sorted columns; shared pair / quad merges from k = 5): widths
     around the 16-byte lane and 1 KiB strip boundaries, heights around the row segments and below the window, few grey
     levels (many ties), ramps and their mirror images (every rank order of a window's columns), a strided batch with an
     unaligned base."""

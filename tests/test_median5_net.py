@@ -1,4 +1,4 @@
-"""The min / max networks of the 5 x 5, 7 x 7 and 9 x 9 median kernels: the committed ipx_median5_net.inc is what the generator emits, and
+"""The min / max networks of the 5 x 5 ... 11 x 11 median kernels: the committed ipx_median5_net.inc is what the generator emits, and
 the emitted text selects the median (all 2^25 0-1 inputs and random byte windows, run on the CPU by tests/tools/median5_net_check.cpp)."""
 import os
 import subprocess
@@ -15,7 +15,7 @@ def test_committed_network_is_the_generated_one():
     assert "correct" in r.stdout and "up to date" in r.stdout
 
 
-@pytest.mark.parametrize("k", [7, 9])
+@pytest.mark.parametrize("k", [7, 9, 11])
 def test_committed_larger_networks_are_the_generated_ones(k):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", f"gen_median{k}_net.py"), "--check"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr

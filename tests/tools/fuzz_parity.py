@@ -126,7 +126,7 @@ while time.time() < t_end:
         fails += check(f"lee{win}", ops.lee_filter(t, win), per_image(lambda x: O.lee_filter_u8(x, win), img), (n, h, w, strided))
     elif op == "median":
         h, w = min(h, 150), min(w, 700)
-        k = int(rng.choice([1, 3, 3, 5, 5, 5, 7, 7, 7, 9, 9, 9, 11, 13, 15, 21, 31]))
+        k = int(rng.choice([1, 3, 3, 5, 5, 5, 7, 7, 7, 9, 9, 9, 11, 11, 11, 13, 15, 21, 31]))
         t, img = make(n, h, w, 1, strided)
         fails += check(f"median{k}", ops.median_blur(t, k), per_image(lambda x: O.median_blur_u8(x, k), img), (n, h, w, strided))
     elif op == "halo":
