@@ -24,6 +24,9 @@
 int ipx_sep_mid(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
                 int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
                 const uint16_t* kx, const uint16_t* ky, int k, const uint8_t* top, const uint8_t* bot);
+int ipx_sep_wave(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,
+                 int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
+                 const uint16_t* kx, const uint16_t* ky, int k, const uint8_t* top, const uint8_t* bot);
 
 namespace {
 
@@ -345,6 +348,14 @@ int ipx_sep_mfma(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h,
     bool fits = true;
     for (int i = 0; i < k; ++i) fits = fits && kx[i] <= 127 && ky[i] <= 127;
     if (!fits) return ipx_sep_mid(st, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, kx, ky, k, top, bot);
+    bool wave_form = true;                                               // ipx_sepwave.hip: one wave per column strip
+#ifdef IPX_DEV
+    if (const char* e = getenv("IPX_WAVE")) wave_form = atoi(e) != 0;
+#endif
+    if (wave_form) {
+        const int rc = ipx_sep_wave(st, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, kx, ky, k, top, bot);
+        if (rc <= 0) return rc;
+    }
     MGeom g;
     g.h = h; g.w = w; g.L = w * c; g.r = k / 2; g.K = k;
     g.s_row = s_row; g.s_img = s_img; g.d_row = d_row; g.d_img = d_img; g.top = top; g.bot = bot;
