@@ -68,6 +68,22 @@ __device__ __forceinline__ void wave_lds_sync()      // orders this wave's LDS w
 
 template <int V> using ic = std::integral_constant<int, V>;
 
+template <int N> __device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Vector-memory operations of a wave that are younger than the DMAs of source tile S + 1 at the top of step S (see the
+// interior loop): the DMAs of tiles S + 2 .. S + RING - 1 and two stores for every step s >= LAG in [S + 1 - RING, S - 1].
+template <int RING, int NLD, int LAG> constexpr int wait_n(int S)
+{
+    int lo = S + 1 - RING;
+    if (lo < LAG) lo = LAG;
+    const int steps = S - lo > 0 ? S - lo : 0;
+    return (RING - 2) * NLD + 2 * steps;
+}
+
 template <int HL, int LAG>
 __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                WGeom g, WTaps taps)
@@ -78,7 +94,10 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
     constexpr int NLD = (16 * NCH + 63) / 64;                    // 16-byte loads per lane and step
     constexpr int OFF = LAG == 2 ? 16 : 8;                       // source tile 0 starts OFF rows above the segment
     constexpr int kSlot = 16 * PS;
-    constexpr int kWaveLds = 2 * kSlot + 64 + 512;               // 2 slots | 64: the last fragment of a row reads 16 bytes past it (zero taps) | the frame pieces' mirror table
+    constexpr int RING = HL <= 48 ? 3 : 2;                       // LDS-DMA ring of the interior loop: RING - 1 source tiles in flight
+    constexpr int kRaw = 1024 * NLD;                             // a source tile as it arrives (lane order: chunk q at byte 16 q)
+    // 2 slots | 64: the last fragment of a row reads 16 bytes past it (zero taps) | the ring (frame pieces: their mirror table)
+    constexpr int kWaveLds = 2 * kSlot + 64 + RING * kRaw;
     // row taps: d0 >= -HL - 15, d0 + 15 <= 64 KSH + 47 - HL + r C; column taps: i0 >= -55, i0 + 3 <= 63 + 15
     constexpr int kPadX = 96, kPadX2 = 192, kPadY = 64, kTapsLds = kPadX + 128 + kPadX2 + kPadY + 32 + 64;
     __shared__ __attribute__((aligned(16))) uint8_t s_all[kWaves * kWaveLds + kTapsLds];
@@ -178,6 +197,7 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
     uint8_t* const dimg = dst + (int64_t)img * g.d_img;
 
     uint8_t* const wlds = s_all + wave * kWaveLds;
+    uint8_t* const wraw = wlds + 2 * kSlot + 64;
     const uint8_t* const a_base = wlds + m * PS + 16 * gq;        // row pass A: + slot, + 16 f for fragment f
     uint32_t whi[NT][4], wlo[NT][4];                              // register windows: high / low bytes of the last 4 source tiles
 #pragma unroll
@@ -229,7 +249,9 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
                     od[j] = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u) | __builtin_amdgcn_perm(o[3], o[2], 0x06020c0cu);
                 }
             }
+#ifndef IPX_WAVE_NOSB
             __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         if (COL) {
 #pragma unroll
@@ -245,60 +267,87 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
     };
 
     if (__builtin_amdgcn_readfirstlane((int)fast)) {
-        // ---- interior: no branch between a load and its use ----------------------------------------------------------
-        // staging chunk q = 64 i + lane of the step's 16 x NCH chunks (a ragged last load re-stages the last chunk)
-        unsigned voff[NLD], loff[NLD];
+        // ---- interior: source rows by LDS-DMA, RING - 1 steps ahead, hand-counted waits, no branch in the loop -----------
+        // A step's 16 x NCH chunks arrive in lane order (chunk q = 64 i + lane at byte 16 q of a ring slot: LDS-DMA writes
+        // base + 16 lane); a copy pass, one step ahead, flips them to signed and lays them out at the fragment pitch.
+        // No lane predicates here: a DMA or copy inside a divergent branch gets duplicated per branch arm by the compiler, which
+        // breaks the instruction counts the waits below rely on.  The lanes past a step's last chunk (half a wave when 16 NCH is
+        // not a multiple of 64) re-load the last chunk into the padding of the ring slot and copy it to the slack bytes.
+        unsigned goff[NLD], loff[NLD];
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            int q = 64 * i + lane;
-            q = q < 16 * NCH ? q : 16 * NCH - 1;
-            const int row = q / NCH, ch = q - row * NCH;
-            voff[i] = (unsigned)(row * (int)g.s_row + 16 * ch);
-            loff[i] = (unsigned)(row * PS + 16 * ch);
+            const int q = 64 * i + lane;
+            const int qc = q < 16 * NCH ? q : 16 * NCH - 1;
+            const int row = qc / NCH, ch = qc - row * NCH;
+            goff[i] = (unsigned)(row * (int)g.s_row + 16 * ch);
+            loff[i] = q < 16 * NCH ? (unsigned)(row * PS + 16 * ch) : (unsigned)(2 * kSlot);
         }
-        u32x4 R[NLD];
         const uint8_t* const sbase = simg + (int64_t)Y0 * g.s_row + xs0;
         const int64_t sstep = 16 * g.s_row, dstep = 16 * g.d_row;
-        auto issue = [&](int S) {
-            const uint8_t* b = sbase + (int64_t)(S < nS ? S : nS - 1) * sstep;
+        auto dma = [&](int s, int rs) {                           // source tile s -> ring slot rs (= s mod RING, wave-uniform)
+            const uint8_t* b = sbase + (int64_t)(s < nS ? s : nS - 1) * sstep;
+            uint8_t* const slot = wraw + rs * kRaw;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) R[i] = ld16(b + voff[i]);
+            for (int i = 0; i < NLD; ++i)
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(b + goff[i]),
+                                                 (void __attribute__((address_space(3)))*)(slot + 1024 * i), 16, 0, 0);
         };
-        auto consume = [&](int slot) {
+        u32x4 cv[NLD];
+        auto copy_read = [&](int rs) {
+            const uint8_t* const slot = wraw + rs * kRaw + 16 * lane;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(wlds + slot * kSlot + loff[i]) = R[i] ^ (u32x4)(0x80808080u);
+            for (int i = 0; i < NLD; ++i) cv[i] = *reinterpret_cast<const u32x4*>(slot + 1024 * i);
+        };
+        auto copy_write = [&](int slot) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(wlds + (loff[i] < 2u * kSlot ? slot * kSlot : 0) + loff[i]) = cv[i] ^ (u32x4)(0x80808080u);
         };
         const unsigned ooff = (unsigned)(m * (int)g.d_row + 16 * gq);
         uint8_t* dT = dimg + (int64_t)(y0 - 16 * LAG) * g.d_row + x0;   // output tile of step S: rows y0 + 16 (S - LAG) ..
         auto st = [&](int J, u32x4 v) { st16_nt(dT + ooff + 64 * J, v); };
         auto none = [](int, u32x4) {};
-        issue(0);
-        consume(0);
-        issue(1);
+        // This wave's vector-memory queue holds its DMAs (NLD per source tile) and its stores (2 per step from step LAG on),
+        // in issue order.  At the top of step S the tile S + 1 must have landed; younger than its DMAs are those of tiles
+        // S + 2 .. S + RING - 1 and the stores of the steps since it was issued (step S + 1 - RING): vmcnt(N(S)).
+        int r0 = 0, r1 = 1 % RING;                                // ring slots of tiles S and S + 1
+#pragma unroll
+        for (int s = 0; s < RING; ++s) dma(s, s);
+        wait_vmcnt<(RING - 1) * NLD>();
+        copy_read(0);
+        copy_write(0);
+        auto head = [&](auto n_c, int S) {                        // top of step S
+            wait_vmcnt<decltype(n_c)::value>();
+            copy_read(r1);
+            dma(S + RING, r0);
+            r0 = r1; r1 = r1 + 1 == RING ? 0 : r1 + 1;
+        };
+        constexpr int kSteady = (RING - 2) * NLD + 2 * (RING - 1);
         // first four steps: the window fills, tiles above the segment are not computed
-        consume(1); issue(2); step(ic<0>{}, ic<0>{}, 0, none); dT += dstep;
-        consume(0); issue(3);
+        head(ic<wait_n<RING, NLD, LAG>(0)>{}, 0); step(ic<0>{}, ic<0>{}, 0, none); copy_write(1); dT += dstep;
+        head(ic<wait_n<RING, NLD, LAG>(1)>{}, 1);
         if constexpr (LAG <= 1) step(ic<1>{}, ic<1>{}, 1, st); else step(ic<1>{}, ic<0>{}, 1, none);
-        dT += dstep;
-        consume(1); issue(4); step(ic<2>{}, ic<1>{}, 0, st); dT += dstep;
-        consume(0); issue(5); step(ic<3>{}, ic<1>{}, 1, st); dT += dstep;
+        copy_write(0); dT += dstep;
+        head(ic<wait_n<RING, NLD, LAG>(2)>{}, 2); step(ic<2>{}, ic<1>{}, 0, st); copy_write(1); dT += dstep;
+        head(ic<wait_n<RING, NLD, LAG>(3)>{}, 3); step(ic<3>{}, ic<1>{}, 1, st); copy_write(0); dT += dstep;
+        static_assert(wait_n<RING, NLD, LAG>(4) == kSteady, "the loop's wait count");
         int S = 4;
         for (; S + 4 <= nS; S += 4) {
-            consume(1); issue(S + 2); step(ic<0>{}, ic<1>{}, 0, st); dT += dstep;
-            consume(0); issue(S + 3); step(ic<1>{}, ic<1>{}, 1, st); dT += dstep;
-            consume(1); issue(S + 4); step(ic<2>{}, ic<1>{}, 0, st); dT += dstep;
-            consume(0); issue(S + 5); step(ic<3>{}, ic<1>{}, 1, st); dT += dstep;
+            head(ic<kSteady>{}, S); step(ic<0>{}, ic<1>{}, 0, st); copy_write(1); dT += dstep;
+            head(ic<kSteady>{}, S + 1); step(ic<1>{}, ic<1>{}, 1, st); copy_write(0); dT += dstep;
+            head(ic<kSteady>{}, S + 2); step(ic<2>{}, ic<1>{}, 0, st); copy_write(1); dT += dstep;
+            head(ic<kSteady>{}, S + 3); step(ic<3>{}, ic<1>{}, 1, st); copy_write(0); dT += dstep;
         }
         const int rem = nS - S;                                   // 0..3 steps left (wave-uniform)
-        if (rem > 0) { consume(1); issue(S + 2); step(ic<0>{}, ic<1>{}, 0, st); dT += dstep; }
-        if (rem > 1) { consume(0); issue(S + 3); step(ic<1>{}, ic<1>{}, 1, st); dT += dstep; }
-        if (rem > 2) { consume(1); step(ic<2>{}, ic<1>{}, 0, st); }
+        if (rem > 0) { head(ic<kSteady>{}, S); step(ic<0>{}, ic<1>{}, 0, st); copy_write(1); dT += dstep; }
+        if (rem > 1) { head(ic<kSteady>{}, S + 1); step(ic<1>{}, ic<1>{}, 1, st); copy_write(0); dT += dstep; }
+        if (rem > 2) { head(ic<kSteady>{}, S + 2); step(ic<2>{}, ic<1>{}, 0, st); }
+        wait_vmcnt<0>();                                          // the DMAs issued past the last tile land before LDS is released
         return;
     }
 
     // ---- frame pieces: image edges, halo rows, ragged strips and rows ------------------------------------------------
     const bool x_in = xs0 >= 0 && xs0 + SW <= g.L;                 // wave-uniform
-    uint16_t* const fixt = reinterpret_cast<uint16_t*>(wlds + 2 * kSlot + 64);   // strip byte -> the strip byte it mirrors
+    uint16_t* const fixt = reinterpret_cast<uint16_t*>(wraw);    // strip byte -> the strip byte it mirrors (2 SW <= 512 bytes)
     const int nl = xs0 < 0 ? (-xs0 < SW ? -xs0 : SW) : 0;         // strip bytes [0, nl) lie left of the row
     const int nr = g.L - xs0 < SW ? (g.L - xs0 > 0 ? g.L - xs0 : 0) : SW;   // strip bytes [nr, SW) lie right of it
     if (!x_in) {
@@ -401,11 +450,15 @@ template <int LAG>
 void launch_hl(hipStream_t st, const uint8_t* src, uint8_t* dst, const WGeom& g, const WTaps& t, int hl)
 {
     const dim3 grid(g.g_blocks + g.f_blocks), block(kThreads);
+    unsigned dyn = 0;
+#ifdef IPX_DEV
+    if (const char* e = getenv("IPX_WAVE_DYNLDS")) dyn = (unsigned)atoi(e);   // dev: extra LDS per block, to lower the occupancy
+#endif
     switch (hl) {
-        case 16: hipLaunchKernelGGL((sep_wave_kernel<16, LAG>), grid, block, 0, st, src, dst, g, t); break;
-        case 32: hipLaunchKernelGGL((sep_wave_kernel<32, LAG>), grid, block, 0, st, src, dst, g, t); break;
-        case 48: hipLaunchKernelGGL((sep_wave_kernel<48, LAG>), grid, block, 0, st, src, dst, g, t); break;
-        default: hipLaunchKernelGGL((sep_wave_kernel<64, LAG>), grid, block, 0, st, src, dst, g, t); break;
+        case 16: hipLaunchKernelGGL((sep_wave_kernel<16, LAG>), grid, block, dyn, st, src, dst, g, t); break;
+        case 32: hipLaunchKernelGGL((sep_wave_kernel<32, LAG>), grid, block, dyn, st, src, dst, g, t); break;
+        case 48: hipLaunchKernelGGL((sep_wave_kernel<48, LAG>), grid, block, dyn, st, src, dst, g, t); break;
+        default: hipLaunchKernelGGL((sep_wave_kernel<64, LAG>), grid, block, dyn, st, src, dst, g, t); break;
     }
 }
 
