@@ -25,7 +25,8 @@
 // slots are static registers).  The FRAME around it -- the first / last strips, the top tile row, the last one or two tile
 // rows: REFLECT_101, the caller's halo rows, ragged widths and heights -- is cut into short pieces that take a generic
 // loop (same arithmetic; per-step addresses, the out-of-row bytes of a strip filled in from the strip's own LDS rows,
-// predicated stores).  The frame is 1-3 % of a large image; its blocks come first in the grid.
+// predicated stores).  The frame is 1-3 % of a large image; its blocks come last in the grid (short pieces that fill the
+// wave slots the interior blocks leave).
 #include "ipx_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -148,9 +149,9 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
     bool fast;
     int strip, t0, nT;
     unsigned img;
-    if (blockIdx.x < g.g_blocks) {                                // frame pieces, dealt round-robin over the XCDs
+    if (blockIdx.x >= g.f_blocks) {                               // frame pieces (after the interior blocks), dealt round-robin over the XCDs
         fast = false;
-        const unsigned wi = blockIdx.x * kWaves + wave;
+        const unsigned wi = (blockIdx.x - g.f_blocks) * kWaves + wave;
         if (wi >= g.g_total) return;                              // (after the only block barrier)
         img = wi / g.g_items;
         unsigned it = wi - img * g.g_items;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
         }
     } else {                                                      // interior segments: neighbouring strips share an XCD's L2
         fast = true;
-        const unsigned wi = xcd_remap(blockIdx.x - g.g_blocks, g.f_blocks) * kWaves + wave;
+        const unsigned wi = xcd_remap(blockIdx.x, g.f_blocks) * kWaves + wave;
         if (wi >= g.f_total) return;
         img = wi / g.f_items;
         const unsigned it = wi - img * g.f_items;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
     const int nS = nT + LAG;                                      // source tiles (steps)
     if (nS < 4) fast = false;                                     // the branch-free loop starts with four steps
 #ifdef IPX_DEV
-    if ((g.dev_mode == 1 && !fast) || (g.dev_mode == 2 && fast) || g.dev_mode == 3) return;
+    if (((g.dev_mode & 3) == 1 && !fast) || ((g.dev_mode & 3) == 2 && fast) || (g.dev_mode & 3) == 3) return;
 #endif
     const int x0 = strip * TXW;
     const int y0 = 16 * t0, y1 = y0 + 16 * nT < g.h ? y0 + 16 * nT : g.h;
@@ -206,33 +207,47 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
         for (int t = 0; t < 4; ++t) { whi[j][t] = 0; wlo[j][t] = 0; }
 
     // One step: row pass of the source tile in LDS slot `slot`, its bytes into window dword TT, column pass of the output
-    // tile LAG tiles back, transposition; `store(J, v)` receives the 16 bytes of this lane for tiles 4 J .. 4 J + 3
-    // (row = lane & 15 of the output tile, byte column 64 J + 16 (lane >> 4) of the strip).
-    auto step = [&](auto tt_c, auto col_c, int slot, auto&& store) {
+    // tile LAG tiles back, transposition; `store(hf, v)` receives this lane's 16 bytes of the output tile:
+    // row 8 hf + (lane & 7), byte column 64 ((lane >> 3) & 1) + 16 (lane >> 4) of the strip.
+    // The eight column tiles go through a software pipeline, one tile per time slot:
+    //   slot t:  F(t + 2) fragment reads | R(t) row products | P(t - 1) pack into the window, C(t - 1) column products |
+    //            O(t - 2) output bytes (+ transposition and store after tiles 3 and 7)
+    // so that every consumer finds its producer one slot back (LDS and matrix-core latencies are covered by the other
+    // stages' instructions instead of being waited out).  NEXTF: the fragments of tiles 0 and 1 of the NEXT step are
+    // read in the last two slots (the interior loop has that tile staged by then); `mid()` runs in slot 3.
+    v4i frc[2][KSH];                                              // fragments carried into the next step (NEXTF)
+    auto step = [&](auto tt_c, auto col_c, auto nextf_c, int slot, auto&& store, auto&& mid) {
         constexpr int TT = decltype(tt_c)::value;
-        constexpr bool COL = decltype(col_c)::value != 0;
+        constexpr bool COL = decltype(col_c)::value != 0, NEXTF = decltype(nextf_c)::value != 0;
         const uint8_t* const ab = a_base + slot * kSlot;
-        // tiles in the order 0 4 1 5 2 6 3 7: the pair (p, p + 4) needs fragments p, p + 4, ... p + 4 KSH and nothing else,
-        // so at most two pairs' fragments are live (the next pair's reads are issued before this pair's products)
-        v4i fr[2][KSH + 1];
-#pragma unroll
-        for (int i = 0; i <= KSH; ++i) fr[0][i] = lds16(ab + 16 * (4 * i));
+        const uint8_t* const abn = a_base + (slot ^ 1) * kSlot;
+        v4i fr[NT][KSH], acc[NT], dhi[NT], dlo[NT];
         uint32_t od[NT];
+        u32x4 ot[NT / 4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            if (p < 3) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i <= KSH; ++i) fr[(p + 1) & 1][i] = lds16(ab + 16 * (p + 1 + 4 * i));
+            for (int ks = 0; ks < KSH; ++ks) fr[j][ks] = NEXTF ? frc[j][ks] : lds16(ab + 16 * (j + 4 * ks));
+#pragma unroll
+        for (int t = 0; t < NT + 2; ++t) {
+            if (t + 2 < NT) {
+#pragma unroll
+                for (int ks = 0; ks < KSH; ++ks) fr[t + 2][ks] = lds16(ab + 16 * (t + 2 + 4 * ks));
+            } else if (NEXTF) {
+#pragma unroll
+                for (int ks = 0; ks < KSH; ++ks) frc[t + 2 - NT][ks] = lds16(abn + 16 * (t + 2 - NT + 4 * ks));
             }
+            if (t < NT) {
+                v4i a = {0, 0, 0, 0};
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int j = p + 4 * half;
-                v4i acc = {0, 0, 0, 0};
-#pragma unroll
-                for (int ks = 0; ks < KSH; ++ks) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(fr[p & 1][half + ks], bh[ks], acc, 0, 0, 0);
+                for (int ks = 0; ks < KSH; ++ks) a = __builtin_amdgcn_mfma_i32_16x16x64_i8(fr[t][ks], bh[ks], a, 0, 0, 0);
+                acc[t] = a;
+            }
+            if (t >= 1 && t - 1 < NT) {
+                const int j = t - 1;
                 // acc[i] = row 4 gq + i, column m; Q8.8 value h = acc + 2^15: (h >> 8) - 128 is byte 1 of acc, (h & 255) - 128 = byte 0 ^ 0x80
-                const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)acc[1], (uint32_t)acc[0], 0x05040100u);
-                const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)acc[3], (uint32_t)acc[2], 0x05040100u);
+                const uint32_t p01 = __builtin_amdgcn_perm((uint32_t)acc[j][1], (uint32_t)acc[j][0], 0x05040100u);
+                const uint32_t p23 = __builtin_amdgcn_perm((uint32_t)acc[j][3], (uint32_t)acc[j][2], 0x05040100u);
                 whi[j][TT] = __builtin_amdgcn_perm(p23, p01, 0x07050301u);
                 wlo[j][TT] = __builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u;
                 if (COL) {
@@ -240,31 +255,47 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
                     const v4i z = {0, 0, 0, 0}, zc = {c0, c0, c0, c0};
                     const v4i ahi = {(int)whi[j][0], (int)whi[j][1], (int)whi[j][2], (int)whi[j][3]};
                     const v4i alo = {(int)wlo[j][0], (int)wlo[j][1], (int)wlo[j][2], (int)wlo[j][3]};
-                    const v4i dhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, bv[TT], z, 0, 0, 0);
-                    const v4i dlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, bv[TT], zc, 0, 0, 0);
-                    uint32_t o[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = ((uint32_t)dhi[i] << 8) + (uint32_t)dlo[i];
-                    // o[i] bits 16..23 = output byte of column 16 j + 4 gq + i, row m of the output tile
-                    od[j] = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u) | __builtin_amdgcn_perm(o[3], o[2], 0x06020c0cu);
+                    dhi[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ahi, bv[TT], z, 0, 0, 0);
+                    dlo[j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(alo, bv[TT], zc, 0, 0, 0);
                 }
             }
+            if (COL && t >= 2) {
+                const int j = t - 2;
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = ((uint32_t)dhi[j][i] << 8) + (uint32_t)dlo[j][i];
+                // o[i] bits 16..23 = output byte of column 16 j + 4 gq + i, row m of the output tile
+                od[j] = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u) | __builtin_amdgcn_perm(o[3], o[2], 0x06020c0cu);
+                if ((j & 3) == 3) {
+                    const int J = j >> 2;
+                    // X[t][q] (register t = tile 4 J + t, lane quarter q = columns 4 q .. 4 q + 3) -> X[q][t]
+                    u32x2v a = __builtin_amdgcn_permlane32_swap(od[4 * J + 0], od[4 * J + 2], false, false);
+                    u32x2v b = __builtin_amdgcn_permlane32_swap(od[4 * J + 1], od[4 * J + 3], false, false);
+                    u32x2v c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+                    u32x2v d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+                    ot[J] = (u32x4){c[0], c[1], d[0], d[1]};      // bytes 64 J + 16 (lane >> 4) .. + 15 of row lane & 15
+                }
+                if (j == NT - 1) {
+                    // rows n and n + 8 trade halves (lanes i and i ^ 8 of every 16): afterwards a store instruction covers 8 whole
+                    // 128-byte rows instead of 16 half rows.  A: rows 0..7, lane (n, q) -> row n & 7, bytes 64 (n >> 3) + 16 q ..;
+                    // B: the same lanes, rows 8..15.
+                    u32x4 va, vb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        va[e] = (uint32_t)__builtin_amdgcn_update_dpp((int)ot[0][e], (int)ot[1][e], 0x128, 0xf, 0xc, false);   // row_ror:8 into lanes 8..15
+                        vb[e] = (uint32_t)__builtin_amdgcn_update_dpp((int)ot[1][e], (int)ot[0][e], 0x128, 0xf, 0x3, false);   // ... into lanes 0..7
+                    }
+                    store(0, va);
+                    store(1, vb);
+                }
+            }
+            if (t == 3) mid();
 #ifndef IPX_WAVE_NOSB
             __builtin_amdgcn_sched_barrier(0);
 #endif
         }
-        if (COL) {
-#pragma unroll
-            for (int J = 0; J < NT / 4; ++J) {
-                // X[t][q] (register t = tile 4 J + t, lane quarter q = columns 4 q .. 4 q + 3) -> X[q][t]
-                u32x2v a = __builtin_amdgcn_permlane32_swap(od[4 * J + 0], od[4 * J + 2], false, false);
-                u32x2v b = __builtin_amdgcn_permlane32_swap(od[4 * J + 1], od[4 * J + 3], false, false);
-                u32x2v c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
-                u32x2v d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-                store(J, (u32x4){c[0], c[1], d[0], d[1]});
-            }
-        }
     };
+    auto nomid = [] {};
 
     if (__builtin_amdgcn_readfirstlane((int)fast)) {
         // ---- interior: source rows by LDS-DMA, RING - 1 steps ahead, hand-counted waits, no branch in the loop -----------
@@ -274,23 +305,42 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
         // breaks the instruction counts the waits below rely on.  The lanes past a step's last chunk (half a wave when 16 NCH is
         // not a multiple of 64) re-load the last chunk into the padding of the ring slot and copy it to the slack bytes.
         unsigned goff[NLD], loff[NLD];
+        int crow[NLD];
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int q = 64 * i + lane;
             const int qc = q < 16 * NCH ? q : 16 * NCH - 1;
             const int row = qc / NCH, ch = qc - row * NCH;
+            crow[i] = row;
             goff[i] = (unsigned)(row * (int)g.s_row + 16 * ch);
             loff[i] = q < 16 * NCH ? (unsigned)(row * PS + 16 * ch) : (unsigned)(2 * kSlot);
         }
-        const uint8_t* const sbase = simg + (int64_t)Y0 * g.s_row + xs0;
-        const int64_t sstep = 16 * g.s_row, dstep = 16 * g.d_row;
+        const int64_t dstep = 16 * g.d_row;
+#ifdef IPX_DEV
+        const bool dev_nost = (g.dev_mode & 4) != 0, dev_nold = (g.dev_mode & 8) != 0;   // timing only: results wrong
+#endif
         auto dma = [&](int s, int rs) {                           // source tile s -> ring slot rs (= s mod RING, wave-uniform)
-            const uint8_t* b = sbase + (int64_t)(s < nS ? s : nS - 1) * sstep;
             uint8_t* const slot = wraw + rs * kRaw;
+#ifdef IPX_DEV
+            if (dev_nold) return;
+#endif
+            const int ytop = Y0 + 16 * (s < nS ? s : nS - 1);     // (past the last tile: re-load it, nobody reads that slot)
+            if (ytop >= 0 && ytop + 16 <= g.h) {                  // wave-uniform: both arms issue NLD DMAs
+                const uint8_t* b = simg + (int64_t)ytop * g.s_row + xs0;
 #pragma unroll
-            for (int i = 0; i < NLD; ++i)
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(b + goff[i]),
-                                                 (void __attribute__((address_space(3)))*)(slot + 1024 * i), 16, 0, 0);
+                for (int i = 0; i < NLD; ++i)
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(b + goff[i]),
+                                                     (void __attribute__((address_space(3)))*)(slot + 1024 * i), 16, 0, 0);
+            } else {                                              // a tile across the top / bottom edge: REFLECT_101 or the caller's halo rows
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    int ys = ytop + crow[i];
+                    ys = ys < -r ? -r : ys > g.h - 1 + r ? g.h - 1 + r : ys;      // farther out: only meets zero taps
+                    const uint8_t* rp = halo_row(simg, g.top, g.bot, ys, g.h, r, g.s_row);
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(rp + xs0 + (goff[i] - (unsigned)(crow[i] * (int)g.s_row))),
+                                                     (void __attribute__((address_space(3)))*)(slot + 1024 * i), 16, 0, 0);
+                }
+            }
         };
         u32x4 cv[NLD];
         auto copy_read = [&](int rs) {
@@ -302,9 +352,14 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
 #pragma unroll
             for (int i = 0; i < NLD; ++i) *reinterpret_cast<u32x4*>(wlds + (loff[i] < 2u * kSlot ? slot * kSlot : 0) + loff[i]) = cv[i] ^ (u32x4)(0x80808080u);
         };
-        const unsigned ooff = (unsigned)(m * (int)g.d_row + 16 * gq);
+        const unsigned ooff = (unsigned)((m & 7) * (int)g.d_row + 64 * (m >> 3) + 16 * gq);
+        const int64_t dhalf = 8 * g.d_row;
         uint8_t* dT = dimg + (int64_t)(y0 - 16 * LAG) * g.d_row + x0;   // output tile of step S: rows y0 + 16 (S - LAG) ..
-        auto st = [&](int J, u32x4 v) { st16_nt(dT + ooff + 64 * J, v); };
+#ifdef IPX_DEV
+        auto st = [&](int hf, u32x4 v) { if (!dev_nost) st16_nt(dT + (hf ? dhalf : 0) + ooff, v); };
+#else
+        auto st = [&](int hf, u32x4 v) { st16_nt(dT + (hf ? dhalf : 0) + ooff, v); };
+#endif
         auto none = [](int, u32x4) {};
         // This wave's vector-memory queue holds its DMAs (NLD per source tile) and its stores (2 per step from step LAG on),
         // in issue order.  At the top of step S the tile S + 1 must have landed; younger than its DMAs are those of tiles
@@ -323,24 +378,30 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
         };
         constexpr int kSteady = (RING - 2) * NLD + 2 * (RING - 1);
         // first four steps: the window fills, tiles above the segment are not computed
-        head(ic<wait_n<RING, NLD, LAG>(0)>{}, 0); step(ic<0>{}, ic<0>{}, 0, none); copy_write(1); dT += dstep;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KSH; ++ks) frc[j][ks] = lds16(a_base + 16 * (j + 4 * ks));
+        auto cw0 = [&] { copy_write(0); };
+        auto cw1 = [&] { copy_write(1); };
+        head(ic<wait_n<RING, NLD, LAG>(0)>{}, 0); step(ic<0>{}, ic<0>{}, ic<1>{}, 0, none, cw1); dT += dstep;
         head(ic<wait_n<RING, NLD, LAG>(1)>{}, 1);
-        if constexpr (LAG <= 1) step(ic<1>{}, ic<1>{}, 1, st); else step(ic<1>{}, ic<0>{}, 1, none);
-        copy_write(0); dT += dstep;
-        head(ic<wait_n<RING, NLD, LAG>(2)>{}, 2); step(ic<2>{}, ic<1>{}, 0, st); copy_write(1); dT += dstep;
-        head(ic<wait_n<RING, NLD, LAG>(3)>{}, 3); step(ic<3>{}, ic<1>{}, 1, st); copy_write(0); dT += dstep;
+        if constexpr (LAG <= 1) step(ic<1>{}, ic<1>{}, ic<1>{}, 1, st, cw0); else step(ic<1>{}, ic<0>{}, ic<1>{}, 1, none, cw0);
+        dT += dstep;
+        head(ic<wait_n<RING, NLD, LAG>(2)>{}, 2); step(ic<2>{}, ic<1>{}, ic<1>{}, 0, st, cw1); dT += dstep;
+        head(ic<wait_n<RING, NLD, LAG>(3)>{}, 3); step(ic<3>{}, ic<1>{}, ic<1>{}, 1, st, cw0); dT += dstep;
         static_assert(wait_n<RING, NLD, LAG>(4) == kSteady, "the loop's wait count");
         int S = 4;
         for (; S + 4 <= nS; S += 4) {
-            head(ic<kSteady>{}, S); step(ic<0>{}, ic<1>{}, 0, st); copy_write(1); dT += dstep;
-            head(ic<kSteady>{}, S + 1); step(ic<1>{}, ic<1>{}, 1, st); copy_write(0); dT += dstep;
-            head(ic<kSteady>{}, S + 2); step(ic<2>{}, ic<1>{}, 0, st); copy_write(1); dT += dstep;
-            head(ic<kSteady>{}, S + 3); step(ic<3>{}, ic<1>{}, 1, st); copy_write(0); dT += dstep;
+            head(ic<kSteady>{}, S); step(ic<0>{}, ic<1>{}, ic<1>{}, 0, st, cw1); dT += dstep;
+            head(ic<kSteady>{}, S + 1); step(ic<1>{}, ic<1>{}, ic<1>{}, 1, st, cw0); dT += dstep;
+            head(ic<kSteady>{}, S + 2); step(ic<2>{}, ic<1>{}, ic<1>{}, 0, st, cw1); dT += dstep;
+            head(ic<kSteady>{}, S + 3); step(ic<3>{}, ic<1>{}, ic<1>{}, 1, st, cw0); dT += dstep;
         }
         const int rem = nS - S;                                   // 0..3 steps left (wave-uniform)
-        if (rem > 0) { head(ic<kSteady>{}, S); step(ic<0>{}, ic<1>{}, 0, st); copy_write(1); dT += dstep; }
-        if (rem > 1) { head(ic<kSteady>{}, S + 1); step(ic<1>{}, ic<1>{}, 1, st); copy_write(0); dT += dstep; }
-        if (rem > 2) { head(ic<kSteady>{}, S + 2); step(ic<2>{}, ic<1>{}, 0, st); }
+        if (rem > 0) { head(ic<kSteady>{}, S); step(ic<0>{}, ic<1>{}, ic<1>{}, 0, st, cw1); dT += dstep; }
+        if (rem > 1) { head(ic<kSteady>{}, S + 1); step(ic<1>{}, ic<1>{}, ic<1>{}, 1, st, cw0); dT += dstep; }
+        if (rem > 2) { head(ic<kSteady>{}, S + 2); step(ic<2>{}, ic<1>{}, ic<0>{}, 0, st, nomid); }
         wait_vmcnt<0>();                                          // the DMAs issued past the last tile land before LDS is released
         return;
     }
@@ -417,8 +478,8 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
         }
     };
     int Sg = 0;                                                   // the step being computed (for the store predicate)
-    auto st_g = [&](int J, u32x4 v) {
-        const int y = y0 + 16 * (Sg - LAG) + m, x = x0 + 64 * J + 16 * gq;
+    auto st_g = [&](int hf, u32x4 v) {
+        const int y = y0 + 16 * (Sg - LAG) + 8 * hf + (m & 7), x = x0 + 64 * (m >> 3) + 16 * gq;
         if (y < y1 && x < g.L) {
             uint8_t* dp = dimg + (int64_t)y * g.d_row + x;
             if (x + 16 <= g.L) st16_nt(dp, v);
@@ -433,14 +494,14 @@ __global__ __launch_bounds__(kThreads, 2) void sep_wave_kernel(const uint8_t* __
         consume_g(slot);
         if (Sg + 1 < nS) issue_g(Sg + 1);
         if (Sg < LAG) {                                           // the window fills
-            if ((Sg & 3) == 0) step(ic<0>{}, ic<0>{}, slot, none_g);
-            else step(ic<1>{}, ic<0>{}, slot, none_g);
+            if ((Sg & 3) == 0) step(ic<0>{}, ic<0>{}, ic<0>{}, slot, none_g, nomid);
+            else step(ic<1>{}, ic<0>{}, ic<0>{}, slot, none_g, nomid);
         } else {
             switch (Sg & 3) {
-                case 0: step(ic<0>{}, ic<1>{}, slot, st_g); break;
-                case 1: step(ic<1>{}, ic<1>{}, slot, st_g); break;
-                case 2: step(ic<2>{}, ic<1>{}, slot, st_g); break;
-                default: step(ic<3>{}, ic<1>{}, slot, st_g); break;
+                case 0: step(ic<0>{}, ic<1>{}, ic<0>{}, slot, st_g, nomid); break;
+                case 1: step(ic<1>{}, ic<1>{}, ic<0>{}, slot, st_g, nomid); break;
+                case 2: step(ic<2>{}, ic<1>{}, ic<0>{}, slot, st_g, nomid); break;
+                default: step(ic<3>{}, ic<1>{}, ic<0>{}, slot, st_g, nomid); break;
             }
         }
     }
@@ -474,16 +535,16 @@ int ipx_sep_wave(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h,
     WGeom g;
     g.h = h; g.w = w; g.L = w * c; g.r = k / 2; g.K = k; g.C = c;
     g.s_row = s_row; g.s_img = s_img; g.d_row = d_row; g.d_img = d_img; g.top = top; g.bot = bot;
-    const int lag = g.r <= 8 ? 1 : 2, off = lag == 2 ? 16 : 8;
+    const int lag = g.r <= 8 ? 1 : 2;
     const int hl = (g.r * c + 15) & ~15;
     g.nstrips = (g.L + TXW - 1) / TXW;
     g.ntiles = (h + 15) / 16;
-    // interior: strips whose source window [x0 - hl, x0 + 128 + hl) lies inside the row; tiles whose source rows
-    // [16 t - off, 16 (t + lag) - off + 16) lie inside the image.  At least 4 tiles and one strip, else everything is frame.
+    // interior: strips whose source window [x0 - hl, x0 + 128 + hl) lies inside the row, all their whole 16-row tiles (source
+    // tiles across the top / bottom edge take the DMA's slow arm).  At least 4 tiles and one strip, else everything is frame.
     g.sl = (hl + TXW - 1) / TXW;
     g.sr = g.L >= hl + TXW ? (g.L - hl) / TXW : 0;
-    g.ta = 1;
-    g.tb = (h + off - 16 * lag) / 16;
+    g.ta = 0;
+    g.tb = h / 16;
     if (g.sr <= g.sl || g.tb - g.ta < 4) { g.sl = g.sr = 0; g.ta = g.tb = 0; }
     const int ns = g.sr - g.sl, nt = g.tb - g.ta;
     // interior segments: aim at one round of resident blocks (2 blocks of 4 waves per CU = 2048 waves), at least 8 tiles each
