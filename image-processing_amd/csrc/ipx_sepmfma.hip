@@ -348,7 +348,9 @@ int ipx_sep_mfma(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h,
     bool fits = true;
     for (int i = 0; i < k; ++i) fits = fits && kx[i] <= 127 && ky[i] <= 127;
     if (!fits) return ipx_sep_mid(st, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, kx, ky, k, top, bot);
-    bool wave_form = true;                                               // ipx_sepwave.hip: one wave per column strip
+    // ipx_sepwave.hip (one wave per column strip) is 1.4-3.5x faster from 1080p frames up; inputs of a few hundred rows and
+    // columns, where its frame pieces are most of the work, stay with the tile kernel below (scripts/dev/wave_shapes.py)
+    bool wave_form = (int64_t)n * h * w * c >= (2 << 20);
 #ifdef IPX_DEV
     if (const char* e = getenv("IPX_WAVE")) wave_form = atoi(e) != 0;
 #endif

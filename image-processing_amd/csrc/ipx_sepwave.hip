@@ -547,14 +547,14 @@ int ipx_sep_wave(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h,
     g.tb = h / 16;
     if (g.sr <= g.sl || g.tb - g.ta < 4) { g.sl = g.sr = 0; g.ta = g.tb = 0; }
     const int ns = g.sr - g.sl, nt = g.tb - g.ta;
-    // interior segments: aim at one round of resident blocks (2 blocks of 4 waves per CU = 2048 waves), at least 8 tiles each
+    // interior segments: aim at one round of resident blocks (2 blocks of 4 waves per CU = 2048 waves), at least 4 tiles each
     int tiles = 1;
     if (ns > 0) {
         const int64_t waves = 2048 - 2048 / 16;                   // (a little room for the frame pieces)
         int64_t segs = waves / ((int64_t)n * ns);
         if (segs < 1) segs = 1;
         tiles = (int)((nt + segs - 1) / segs);
-        if (tiles < 8) tiles = 8;
+        if (tiles < 4) tiles = 4;
 #ifdef IPX_DEV
         if (const char* e = getenv("IPX_WAVE_TILES")) { if (atoi(e) > 0) tiles = atoi(e); }
 #endif

@@ -277,6 +277,53 @@ def test_large_kernels_matrix_core_path(dev, cn):
         np.testing.assert_array_equal(got[i] if cn > 1 else got[i][:, :, 0], want)
 
 
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_large_kernels_wave_per_strip_path(dev, cn):
+    """inputs of 2 MB and more take ipx_sepwave.hip (one wave per 128-byte column strip): interior segments (LDS-DMA ring,
+    reflect-aware at the top / bottom edge), frame pieces (first / last strips, ragged widths and heights), both column-pass
+    lags (k <= 17 and above), asymmetric taps, extreme values, batches with padded strides, row blocks with halo rows."""
+    rng = np.random.default_rng(60 + cn)
+    def taps(k):
+        t = rng.integers(0, 9, k)
+        t[rng.integers(0, k)] += 256 - t.sum()
+        while t.max() > 127:
+            i, j = int(t.argmax()), int(t.argmin())
+            t[i] -= 20; t[j] += 20
+        assert t.sum() == 256 and t.min() >= 0
+        return [int(v) for v in t]
+    wpx = lambda nbytes: (nbytes + cn - 1) // cn                      # pixels per row for about nbytes row bytes
+    # (h, row bytes): whole strips and tiles; ragged last strip (L % 128, L % 16); h % 16 != 0; few tall strips; one wide tile row band
+    for (h, nb), k in (((1024, 2048), 9), ((1000, 2100), 17), ((1031, 2061), 19), ((4100, 520), 31), ((70, 30000), 13), ((2050, 1030), 25)):
+        w = wpx(nb)
+        img = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
+        kx, ky = taps(k), taps(k)
+        np.testing.assert_array_equal(host(ops.sep_filter_q8(dev_t(img, dev), kx, ky)), O.sep_filter_q8_u8(img, kx, ky),
+                                      err_msg=f"{img.shape} k={k}")
+    ext = np.where(rng.random((900, wpx(2400), cn)) < 0.5, 0, 255).astype(np.uint8)
+    ext = ext[:, :, 0] if cn == 1 else ext
+    for k in (11, 31):
+        np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(ext, dev), k)), O.gaussian_blur_u8(ext, k))
+    w = wpx(1500)
+    big = rng.integers(0, 256, (3, 520, (w + 10) * cn + 5), dtype=np.uint8)
+    view = dev_t(big, dev)[:, 3:515, 2:2 + w * cn].unflatten(2, (w, cn))         # strided batch, unaligned base
+    ref_in = big[:, 3:515, 2:2 + w * cn].reshape(3, 512, w, cn)
+    for k in (15, 21):
+        got = host(ops.gaussian_blur(view, k))
+        for i in range(3):
+            want = O.gaussian_blur_u8(ref_in[i] if cn > 1 else ref_in[i][:, :, 0], k)
+            np.testing.assert_array_equal(got[i] if cn > 1 else got[i][:, :, 0], want, err_msg=f"batch k={k}")
+    img = rng.integers(0, 256, (1400, wpx(1800), cn) if cn > 1 else (1400, wpx(1800)), dtype=np.uint8)
+    t = dev_t(img, dev)                                                         # row blocks with halo rows == the whole image cropped
+    for k in (9, 31):
+        r = k // 2
+        want = O.gaussian_blur_u8(img, k)
+        for y0, y1 in ((0, 1200), (100, 1400), (37, 1301)):
+            top = t[y0 - r:y0] if y0 > 0 else None
+            bot = t[y1:y1 + r] if y1 < 1400 else None
+            got = host(ops.gaussian_blur(t[y0:y1], k, top_halo=top, bottom_halo=bot))
+            np.testing.assert_array_equal(got, want[y0:y1], err_msg=f"rows {y0}:{y1} k={k}")
+
+
 def test_gaussian_power_of_two_symmetric_taps(dev):
     """taps g * [1 a (b a) 1] with g a power of two (cv2's own 3- and 5-tap Gaussians among them) run in packed 16-bit
     arithmetic (sep_pow2_kernel); mixed scales per axis, the overflow boundary (which must fall back), 0/255 images."""
