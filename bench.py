@@ -59,30 +59,185 @@ def cpu_baseline(frames: int, passes: int):
                       "A port, not the reference: OpenCV is absent from this image"}
 
 
-def spawn_ranks(n: int) -> int:
-    """Run `n` ranks of this script (one per GPU) as child processes and relay rank 0's output; returns the exit code.
-    The parent makes no GPU call (children are started with subprocess, nothing is exec'd over an initialised process)."""
+def spawn_ranks(n: int, rank_timeout: float) -> int:
+    """Run `n` ranks of this script (one per GPU) as child processes, watch ALL of them, and relay rank 0's output.
+    The first rank that exits non-zero ends the run: the others are terminated (then killed) and the exit code is non-zero,
+    with that rank's stderr tail -- a rank that dies before the rendezvous must not leave the rest waiting in it.  The same
+    after `rank_timeout` seconds without an exit.  An 'address already in use' failure of the rendezvous is retried on a
+    new port.  The parent makes no GPU call (children are started with subprocess, nothing is exec'd over an initialised
+    process)."""
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0 = procs[0].communicate()[0]
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0)
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+    import tempfile
+
+    def tail(f, nbytes=3000):
+        f.flush(); f.seek(0, os.SEEK_END)
+        size = f.tell(); f.seek(max(0, size - nbytes))
+        return f.read().decode("utf-8", "replace")
+
+    def stop(procs):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    for attempt in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        procs, outs, errs = [], [], []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            outs.append(tempfile.TemporaryFile())
+            errs.append(tempfile.TemporaryFile())
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=outs[r], stderr=errs[r]))
+        t0 = time.time()
+        failed, timed_out = None, False
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t0 > rank_timeout:
+                timed_out = True
+                break
+            time.sleep(0.1)
+        if failed is None and not timed_out:
+            sys.stdout.write(tail(outs[0], 1 << 22))
+            sys.stdout.flush()
+            sys.stderr.write(tail(errs[0]))
+            return 0
+        stop(procs)
+        if failed is not None:
+            r, c = failed
+            text = tail(errs[r])
+            if attempt < 2 and ("address already in use" in text.lower() or "EADDRINUSE" in text):
+                print(f"bench.py: rendezvous port {port} was taken, retrying on another one", file=sys.stderr)
+                continue
+            print(f"bench.py: rank {r} exited with code {c}; the other ranks were stopped.  Its stderr ends:\n{text}", file=sys.stderr)
+            return 1
+        alive = [r for r, c in enumerate(codes) if c is None]
+        print(f"bench.py: no result after --rank-timeout {rank_timeout:.0f} s; ranks still running: {alive} (stopped).  "
+              f"stderr of rank {alive[0]} ends:\n{tail(errs[alive[0]])}", file=sys.stderr)
         return 1
-    return 0
+    return 1
+
+
+def run_rowpart(args, torch, dist, ops, dev, rank, world):
+    """BASELINE.json configs[4]: one S x S gray image, rows split into contiguous blocks over the ranks (SURVEY.md 8(e) case 2).
+    One step = cv2.equalizeHist of the whole image (local 256-bin histogram -> all-reduce(sum) of 1 KiB -> the same table on
+    every rank -> local table pass) + a 3x3 box filter (one halo row sent to and received from each neighbour: 2 x S bytes per
+    rank and direction).  Strong scaling: the image is fixed, value = S*S pixels / step time (max over ranks)."""
+    from ipx.sharder import RowPartition
+    S = args.rowpart_size
+    part = RowPartition(S, rank, world, ops=ops)
+    rows = part.y1 - part.y0
+    g = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    local = torch.empty((rows, S), dtype=torch.uint8, device=dev)
+    for y in range(0, rows, 2048):                             # filled in pieces: a 1 GiB host tensor at once is not needed
+        n = min(2048, rows - y)
+        local[y:y + n] = torch.randint(0, 256, (n, S), dtype=torch.uint8, generator=g).to(dev)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        eq = part.equalize_hist(local)
+        if ev is not None:
+            ev[1].record()
+        bx = part.conv3(local, "box3")
+        if ev is not None:
+            ev[2].record()
+        return eq, bx
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(30):                                        # clock ramp: a FIXED count -- every step holds collectives, so
+        step()                                                 # all ranks must run the same number of them
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    for i in range(args.steps):
+        step(events[i])
+    torch.cuda.synchronize()
+    rank_ms = [dt / args.steps * 1e3]
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = [None] * world
+        dist.all_gather_object(every, dt)                     # (an object gather: works with RCCL and with the gloo rehearsal alike)
+        rank_ms = [float(v) / args.steps * 1e3 for v in every]
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        return None
+    px_local = rows * S
+    ops_t = {}
+    for j, (name, kern) in enumerate((("equalize_hist_gray", "hist_partial_kernel+hist_finish_kernel+lut_kernel (+ 1 KiB all-reduce)"),
+                                      ("box3_gray", "conv3_kernel<BOX,1> (+ halo rows)"))):
+        s = sum(events[i][j].elapsed_time(events[i][j + 1]) for i in range(args.steps)) / args.steps * 1e-3
+        gbs = px_local * 2 / s / 1e9
+        ops_t[name] = {"kernel": kern, "us_per_step_rank0": round(s * 1e6, 1), "algorithmic_B_per_px": 2, "GBps": round(gbs, 1),
+                       "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4), "timing": "HIP events around the op (collectives included) in K instrumented steps, rank 0's rows"}
+    dom_name = max(ops_t, key=lambda k: ops_t[k]["us_per_step_rank0"])
+    dom = ops_t[dom_name]
+    cpu = None
+    if args.cpu_sample > 0 and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import numpy as np
+        import coracle as CO
+        threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+        sample = np.random.default_rng(0).integers(0, 256, (min(4096, S), S), dtype=np.uint8)
+        CO.box3_u8(sample[:64])
+        t1 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t1 < 15.0 and done < args.cpu_sample:   # bounded: ~15 s of CPU work at most
+            CO.equalize_hist_u8(sample)
+            CO.box3_u8(sample)
+            done += 1
+        dtc = time.perf_counter() - t1
+        cpu = {"value": round(done * sample.size / 1e6 / dtc, 2), "unit": "megapixels/s", "cores": threads, "kind": "port",
+               "sample": f"{done} passes of equalizeHist + 3x3 box over a {sample.shape[0]} x {S} gray block, C oracle (OpenMP, {threads} threads, "
+                         f"{dtc:.1f} s of CPU work); host reports {os.cpu_count()} logical CPUs.  A port, not the reference: OpenCV is absent from this image"}
+    return {
+        "metric": "megapixels/sec (whole node) for conv3x3 + hist-eq on 4K RGB; % of HBM roofline",
+        "value": round(S * S / 1e6 / (dt / args.steps), 1), "unit": "megapixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "ranks_seen": dist.get_world_size() if world > 1 else 1, "ms_per_step_per_rank": [round(v, 3) for v in rank_ms],
+        "config": {"workload": f"BASELINE.json configs[4]: one {S} x {S} gray image row-partitioned over the ranks, hist-eq + 3x3 box per step",
+                   "rows_per_rank": rows, "image": f"{S}x{S} u8 gray",
+                   "messages_per_step_and_rank": f"halo exchange: {S} bytes to and {S} bytes from each neighbour (<= 2 x {S // 1024} KiB each way); "
+                                                 "histogram all-reduce(sum): 256 x int32 = 1 KiB",
+                   "parallelism": f"{world} x one process per GPU, contiguous row blocks, send/recv of halo rows + all-reduce of the histogram (RCCL)"},
+        "roofline": {"bound": "hbm", "kernel": dom["kernel"], "op": dom_name, "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dom["frac_of_8TBps"], "traffic": None,
+                     "traffic_source": "not collected for this workload (profiles/ holds the PMC passes of the pipeline workload)",
+                     "algorithmic_bytes_per_launch": px_local * 2, "launch_us": dom["us_per_step_rank0"]},
+        "cpu_baseline": cpu, "kernels": ops_t,
+    }
 
 
 def main():
@@ -97,6 +252,12 @@ def main():
                          "Sobel, equalize table pass (Sobel reads the gray batch right after it was written); table_first = the "
                          "round-1 order (equalize finished before Sobel); gauss_last = sobel_mid with the Gaussian at the end")
     ap.add_argument("--ops-table", action="store_true", help="also time ops that are not part of the step, back to back")
+    ap.add_argument("--rank-timeout", type=float, default=420.0, help="--gpus N without a launcher: seconds before silent ranks are stopped")
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "rowpart"],
+                    help="pipeline = BASELINE configs[1] on a resident batch per GPU (weak scaling, the headline line); rowpart = "
+                         "BASELINE configs[4]: ONE gray image of --rowpart-size^2 pixels split into contiguous row blocks over the ranks, "
+                         "hist-eq (1 KiB histogram all-reduce) + 3x3 box (one halo row exchanged each way) per step (strong scaling)")
+    ap.add_argument("--rowpart-size", type=int, default=32768, help="side of the square gray image of --workload rowpart")
     args = ap.parse_args()
 
     # --gpus N without a launcher: start N ranks of this script as CHILD processes, before this process touches the GPU
@@ -107,7 +268,12 @@ def main():
     if env_world is not None and int(env_world) != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={env_world} set by the launcher")
     if env_world is None and args.gpus > 1:
-        sys.exit(spawn_ranks(args.gpus))
+        sys.exit(spawn_ranks(args.gpus, args.rank_timeout))
+
+    if os.environ.get("IPX_BENCH_FAIL_RANK") is not None and os.environ.get("IPX_BENCH_FAIL_RANK") == os.environ.get("RANK"):
+        sys.exit(3)                                           # test knob: this rank dies before the rendezvous
+    if os.environ.get("IPX_BENCH_HANG") and os.environ.get("RANK") is not None:
+        time.sleep(3600)                                      # test knob: a silent rank
 
     import torch
     import torch.distributed as dist
@@ -130,6 +296,15 @@ def main():
             dist.init_process_group(backend)
     L.load()
     L.call("ipx_check_device")
+
+    if args.workload == "rowpart":
+        out = run_rowpart(args, torch, dist, ops, dev, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if out is not None:
+            print(json.dumps(out))
+        return
 
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -229,8 +404,12 @@ def main():
     for i in range(lat_steps):
         step_one(lat_events[i])
     torch.cuda.synchronize()
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = [None] * world
+        dist.all_gather_object(every, dt)                     # (an object gather: works with RCCL and with the gloo rehearsal alike)
+        rank_ms = [float(v) / args.steps * 1e3 for v in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
@@ -334,6 +513,7 @@ def main():
             "value": round(value, 1), "unit": "megapixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
+            "ranks_seen": dist.get_world_size() if world > 1 else 1, "ms_per_step_per_rank": [round(v, 3) for v in rank_ms],
             "config": {"workload": "BASELINE.json configs[1]: 3840x2160 RGB, 5x5 Gaussian + Sobel (3x3) + hist-eq "
                                    "(incl. BGR->gray), batch resident in HBM",
                        "batch_per_gpu": B, "image": "3840x2160x3 u8 BGR interleaved",

@@ -344,28 +344,38 @@ int equalize_with_workspace(hipStream_t st, const uint8_t* src, uint8_t* dst, in
     hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, st, ws.partial, nparts,
                        (const uint32_t*)nullptr, hist_out_dev, lut);
     IPX_LAUNCH_CHECK("hist_finish_kernel");
-    // the table pass walks the batch back to front: what the histogram pass read last is still in the Infinity Cache
+    // the table pass (default cache policy up to kNtHistThenLut bytes: what the histogram pass read is still in the Infinity Cache)
     return ipx_lut_dev_u8((void*)st, src, dst, n, h, w, 1, s_row, s_img, d_row, d_img, lut, 256);
 }
 
 // ---- scratch of the no-allocation entry point ---------------------------------------------------------------------
 // One array per GPU, held until the process ends.  `scratch` is a host-side stand-in for the symbol, NOT a device
-// address: host code only ever uses the pointer hipGetSymbolAddress returns for the current device.
+// address: host code only ever uses the pointer hipGetSymbolAddress returned for the device the call's stream belongs to.
 constexpr size_t kScratchBytes = IPX_NOALLOC_SCRATCH_BYTES;           // partial counts (<= 1 MiB) + histograms + tables of <= 256 images
 constexpr int kMaxDevices = 64;
 static __device__ __align__(256) uint8_t scratch[kScratchBytes];
-std::atomic<uint8_t*> g_scratch_ptr[kMaxDevices];      // per device, filled on the first call with that device current
+std::atomic<uint8_t*> g_scratch_ptr[kMaxDevices];      // per device, filled on the first call on a stream of that device
                                                         // (two racing first calls both look up the same address)
 
-int scratch_for_current_device(const char* fn, uint8_t** out)
+// The scratch of the device that owns `st` (every GPU holds its own copy of the array at its own address).  The first call
+// per device looks the address up with that device current (restored afterwards); that look-up may load the code object, so it
+// belongs outside a graph capture -- later calls only read the cached pointer.
+int scratch_for_stream(const char* fn, hipStream_t st, uint8_t** out)
 {
     int dev = -1;
-    IPX_HIP(hipGetDevice(&dev));
+    if (hipStreamGetDevice(st, &dev) != hipSuccess) {             // (the null stream: the current device)
+        (void)hipGetLastError();
+        IPX_HIP(hipGetDevice(&dev));
+    }
     if (dev < 0 || dev >= kMaxDevices) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: device index %d outside 0..%d", fn, dev, kMaxDevices - 1);
     uint8_t* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
     if (!ptr) {
+        int cur = -1;
+        IPX_HIP(hipGetDevice(&cur));
+        if (cur != dev) IPX_HIP(hipSetDevice(dev));
         void* p = nullptr;
         hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (cur != dev) (void)hipSetDevice(cur);
         if (e != hipSuccess || !p)
             return ipx_fail(IPX_ERR_HIP, "%s: hipGetSymbolAddress(scratch) failed on device %d: %s", fn, dev, hipGetErrorString(e));
         ptr = (uint8_t*)p;
@@ -464,7 +474,7 @@ int ipx_equalize_hist_noalloc_u8(void* stream, const uint8_t* src, uint8_t* dst,
         return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: a batch of %d images needs %zu bytes of scratch, the built-in array holds %zu "
                         "(use ipx_equalize_hist_u8 with a workspace)", fn, n, need, kScratchBytes);
     uint8_t* ws = nullptr;
-    if (int rc = scratch_for_current_device(fn, &ws)) return rc;
+    if (int rc = scratch_for_stream(fn, (hipStream_t)stream, &ws)) return rc;
     // Nothing in the scratch has to start at zero: every partial count, histogram bin and table entry that is read
     // is written first by this call's own kernels, so the previous call's contents are simply overwritten.
     return equalize_with_workspace((hipStream_t)stream, src, dst, n, h, w, src_row_stride, src_img_stride,

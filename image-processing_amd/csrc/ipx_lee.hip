@@ -41,10 +41,13 @@ __device__ __forceinline__ f2 div_by_const(f2 a, float n, float c)
     return fma2(fma2(-nn, y, a), cc, y);
 }
 
-// fl(a / b) for 2^-60 < a, 2^-8 < b < 2^20, a <= b (the Lee gain var / (var + q)): the operation sequence of the hardware's
-// own IEEE division (v_div_scale, v_rcp, 4 FMAs + 1 multiply for the refinement, v_div_fmas, v_div_fixup) with the parts
-// that only act on extreme exponents, zeros, infinities and NaNs left out: v_div_scale does not scale and v_div_fixup passes
-// the quotient through in this range, so the result is bit-identical to a / b (every Lee parity test goes through it).
+// fl(a / b) for the two divisions of the Lee filter: the gain var / (var + q) (2^-60 < a <= b, 2^-8 < b < 2^20) and, in the forms
+// without a table, q = fl(mean^2) / fl(mean + 1e-12) for window sums S > 0 (2^-14 < a < 2^16, 2^-7 < b < 2^8, quotient < 2^8).
+// It is the operation sequence of the hardware's own IEEE division (v_div_scale, v_rcp, 4 FMAs + 1 multiply for the refinement,
+// v_div_fmas, v_div_fixup) with the parts that only act on extreme exponents, zeros, infinities and NaNs left out: in both ranges
+// the operands' and the quotient's exponents stay far from where v_div_scale scales and v_div_fixup intervenes, so the result is
+// bit-identical to a / b.  tests/test_oracle_golden.py runs the sequence (fmaf on the CPU, the reciprocal seed also one ulp off
+// either way) over EVERY window sum of 49, 81 and 121 values and a sweep of gains; every Lee parity test goes through it on the GPU.
 __device__ __forceinline__ f2 div_safe_range(f2 a, f2 b)
 {
     f2 r = f2{__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};

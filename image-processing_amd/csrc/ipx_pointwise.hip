@@ -343,6 +343,14 @@ int ipx_lut_multi_u8(void* stream, const uint8_t* src, uint8_t* const* dsts, int
         if (int rc = ipx_check_image_args(fn, src, dsts[j], n, h, w, c, c, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride)) return rc;
         for (int i = 0; i < j; ++i)
             if (dsts[i] == dsts[j]) return ipx_fail(IPX_ERR_INVALID, "%s: destinations %d and %d are the same buffer", fn, i, j);
+        // with k > 1 every table reads the source after destination j has been written: no destination may overlap it
+        // (k = 1 in place is the plain table pass and stays allowed)
+        if (k > 1) {
+            const int64_t s_span = (int64_t)(n - 1) * src_img_stride + (int64_t)(h - 1) * src_row_stride + (int64_t)w * c;
+            const int64_t d_span = (int64_t)(n - 1) * dst_img_stride + (int64_t)(h - 1) * dst_row_stride + (int64_t)w * c;
+            if (dsts[j] < src + s_span && src < dsts[j] + d_span)
+                return ipx_fail(IPX_ERR_INVALID, "%s: destination %d overlaps the source (allowed only for k = 1)", fn, j);
+        }
         md.p[j] = dsts[j];
     }
     PwGeom g = make_geom(h, (int64_t)w * c, 1, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride, kUnit);

@@ -65,18 +65,49 @@ class BatchSharder:
             stream = torch.cuda.Stream(device=dev) if cuda else None
             ctx = torch.cuda.stream(stream) if cuda else _Null()
             with ctx:
+                # persistent pinned staging (as GpuBackend in app.py): two upload buffers used in turn -- a buffer is reused
+                # only after the event behind its last H2D copy -- and one download buffer; `.pin_memory()` per image is a
+                # page-locking system call per upload, a pageable D2H copy of a 4K colour frame takes 5x the pinned one
+                up = [None, None]
+                up_done = [None, None]
+                down = [None]
+
+                def upload(a, k):
+                    if not cuda or a.dtype != np.uint8 or a.size == 0:
+                        return torch.from_numpy(a).to(dev)
+                    j = k & 1
+                    if up[j] is None or up[j].numel() < a.size:
+                        up[j] = torch.empty(max(a.size, 1 << 20), dtype=torch.uint8).pin_memory()
+                    elif up_done[j] is not None:
+                        up_done[j].synchronize()
+                    view = up[j][:a.size].view(a.shape)
+                    view.numpy()[...] = a
+                    t = view.to(dev, non_blocking=True)
+                    up_done[j] = torch.cuda.Event()
+                    up_done[j].record(stream)
+                    return t
+
+                def download(t):
+                    t = t.contiguous()
+                    n = t.numel() * t.element_size()
+                    if not cuda or t.dtype != torch.uint8 or n == 0:
+                        return t.to("cpu").numpy()
+                    if down[0] is None or down[0].numel() < n:
+                        down[0] = torch.empty(max(n, 1 << 20), dtype=torch.uint8).pin_memory()
+                    view = down[0][:n].view(t.shape)
+                    view.copy_(t, non_blocking=True)
+                    stream.synchronize()
+                    return np.array(view.numpy())                   # the buffer is reused by the next result
+
                 pending = []
-                for i in range(di, len(images), len(self.devices)):
-                    a = np.ascontiguousarray(images[i])
-                    t = torch.from_numpy(a)
-                    t = t.pin_memory().to(dev, non_blocking=True) if cuda else t
-                    res = fn(self.ops, t)
+                for k, i in enumerate(range(di, len(images), len(self.devices))):
+                    res = fn(self.ops, upload(np.ascontiguousarray(images[i]), k))
                     pending.append((i, res))
                 for i, res in pending:                              # copies back queue behind the kernels
                     if isinstance(res, tuple):
-                        out[i] = tuple(r.to("cpu").numpy() for r in res)
+                        out[i] = tuple(download(r) for r in res)
                     else:
-                        out[i] = res.to("cpu").numpy()
+                        out[i] = download(res)
                 if cuda:
                     stream.synchronize()
         except BaseException as e:  # noqa: BLE001 - reported to the caller thread

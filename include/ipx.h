@@ -131,7 +131,10 @@ int ipx_equalize_hist_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
  * ipx_hist_workspace_bytes(n, h, w) exceeds IPX_NOALLOC_SCRATCH_BYTES are rejected with IPX_ERR_UNSUPPORTED
  * (any batch of up to 256 images fits, whatever the image size).  All calls on one GPU share that GPU's array: calls that
  * overlap in time on one GPU (two streams, two threads) race -- serialise them.  Nothing in the array has to
- * start at zero (every word that is read is written first by the same call). */
+ * start at zero (every word that is read is written first by the same call).  The array used is that of the GPU `stream`
+ * belongs to (the current device for the null stream).  The FIRST call per GPU looks the array's address up
+ * (hipGetSymbolAddress, which may load the code object): make one call outside a graph capture first; every later
+ * call can be captured (tests/test_zz_no_alloc.py captures and replays one). */
 #define IPX_NOALLOC_SCRATCH_BYTES (1536u * 1024u)
 int ipx_equalize_hist_noalloc_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
                                  int64_t src_row_stride, int64_t src_img_stride,

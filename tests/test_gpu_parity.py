@@ -204,6 +204,11 @@ def test_multi_table_pass(dev):
     ptrs = (ctypes.c_void_p * 2)(out.data_ptr(), out.data_ptr())                 # the same destination twice
     with pytest.raises(L.IpxError):
         L.call("ipx_lut_multi_u8", None, t.data_ptr(), ctypes.cast(ptrs, ctypes.c_void_p), 2, 2, 8, 8, 1, 8, 64, 8, 64, tab.data_ptr(), 0)
+    out2 = torch.empty_like(t)
+    ptrs = (ctypes.c_void_p * 2)(t.data_ptr(), out2.data_ptr())                  # a destination that is the source (k > 1)
+    with pytest.raises(L.IpxError) as e:
+        L.call("ipx_lut_multi_u8", None, t.data_ptr(), ctypes.cast(ptrs, ctypes.c_void_p), 2, 2, 8, 8, 1, 8, 64, 8, 64, tab.data_ptr(), 0)
+    assert "overlaps the source" in str(e.value)
 
 
 @pytest.mark.parametrize("shape", SHAPES)

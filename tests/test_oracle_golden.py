@@ -285,3 +285,52 @@ int main(void) {
     exe = tmp_path / "mk"
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"], check=True)
     assert subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip() == "0"
+
+
+def test_lee_division_sequence_on_the_operands_the_kernel_feeds_it(tmp_path):
+    """ipx_lee.hip's div_safe_range(a, b) = the hardware division's refinement steps without its range handling.  It is used for
+    the gain var / (var + q) (a <= b) AND, in the 7 x 7 ... 11 x 11 forms without a table, for q = fl(mean^2) / fl(mean + 1e-12),
+    where a reaches 65025 against b <= 255 (quotient up to 255).  For every window sum S > 0 of n = 49, 81, 121 values the
+    sequence must give fl(a / b) -- also when the reciprocal seed (v_rcp_f32: 1 ulp) is off by one unit either way -- and for a
+    sample of gains.  Plain C with fmaf, gcc, no GPU."""
+    import shutil, subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    src = tmp_path / "dv.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <stdint.h>
+#include <string.h>
+#include <math.h>
+static float seq(float a, float b, int ulp) {
+    float r = 1.0f / b;
+    uint32_t u; memcpy(&u, &r, 4); u += ulp; memcpy(&r, &u, 4);
+    r = fmaf(fmaf(-b, r, 1.0f), r, r);
+    float q = a * r;
+    q = fmaf(fmaf(-b, q, a), r, q);
+    return fmaf(fmaf(-b, q, a), r, q);
+}
+int main(void) {
+    const int ns[] = {49, 81, 121};
+    long bad = 0, n_checked = 0;
+    for (int ni = 0; ni < 3; ++ni) {
+        const float n = (float)ns[ni];
+        for (int S = 1; S <= 255 * ns[ni]; ++S) {
+            const float mean = (float)S / n, a = mean * mean, b = mean + 1e-12f;
+            for (int ulp = -1; ulp <= 1; ++ulp) { if (seq(a, b, ulp) != a / b) ++bad; ++n_checked; }
+            /* gains with this q and a sweep of variances (var = t / n for integers t, as the kernel forms them) */
+            const float q = a / b;
+            for (int t = 1; t < 4000000; t = t * 3 + 1) {
+                const float var = (float)t / n;
+                for (int ulp = -1; ulp <= 1; ++ulp) { if (seq(var, var + q, ulp) != var / (var + q)) ++bad; ++n_checked; }
+            }
+        }
+    }
+    printf("%ld %ld\n", bad, n_checked);
+    return 0;
+}
+""")
+    exe = tmp_path / "dv"
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"], check=True)
+    bad, checked = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert bad == "0" and int(checked) > 2_000_000
