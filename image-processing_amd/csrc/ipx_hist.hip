@@ -6,8 +6,14 @@
 //   (all lanes, one bin) costs the same as white noise.  The 32 copies are folded with a rotated
 //   (conflict-free) read and the block stores its 256 partial counts with plain coalesced stores: no
 //   global atomics, no zero-fill, bitwise reproducible.
-// hist_finish_kernel: one block per image sums the per-block partials and (optionally) builds the
-//   equalization table with an LDS scan, in float32 exactly as OpenCV does.
+// hist_tail: for images cut into 65 or more blocks, the LAST block to arrive at a ticket (one device-scope atomic per block;
+//   the tickets live in the caller's workspace, start at zero and are set back to zero by the block that wins them) sums
+//   the partial counts, in two levels (groups of 32 blocks, then <= 32 group sums: one round of loads each), and builds the
+//   equalization table with an LDS scan, in float32 exactly as OpenCV does: no second launch between the histogram pass and
+//   the table pass.
+// hist_finish_kernel: the same sum and table construction as a kernel of its own, one block per image: batches of images
+//   of fewer than 65 blocks each (where it measured faster), and ipx_equalize_lut_u8 (a row-partitioned image all-reduces
+//   its histogram first).
 #include "ipx_common.h"
 #include <stdlib.h>
 #include <atomic>
@@ -35,9 +41,152 @@ __device__ __forceinline__ void count4(uint32_t* s_hist, uint32_t x, unsigned co
     atomicAdd(&s_hist[((x >> 24) << 5) | copy], 1u);
 }
 
+// ---- in-kernel finish ---------------------------------------------------------------------------------------------
+constexpr unsigned kTicketImages = 4096;       // one ticket per image (the only level, or the second of two)
+constexpr unsigned kTicketGroups = 128;        // first-level tickets: one per group of kGroup blocks
+constexpr size_t kTicketBytes = (size_t)(kTicketImages + kTicketGroups) * sizeof(uint32_t);    // 66 x 256 B, at the
+                                               // START of every workspace: the same words whatever the batch geometry
+constexpr unsigned kGroup = 32;                // blocks per first-level group; at most kGroup * kGroup blocks per image
+constexpr unsigned kTicketMinBlocks = 65;      // images cut into fewer blocks keep the separate finish kernel (see make_tail)
+
+struct HistTail {
+    uint32_t* partial;      // [n][blocks per image][256]
+    uint32_t* partial2;     // [n][ngroups][256]   (ngroups > 1 only)
+    uint32_t* tickets;      // null: partial counts only, the host launches hist_finish_kernel
+    uint32_t* hist_out;     // may be null
+    uint8_t* lut_out;       // may be null
+    unsigned ngroups;       // ceil(blocks per image / kGroup), <= kGroup
+};
+
+// Counts that cross blocks (and so, possibly, XCDs, whose L2s are not coherent with each other) move with device-scope
+// relaxed atomics: the store is written through to memory (sc1), the load bypasses the caches.  NO device-scope fence
+// anywhere: on gfx950 such a fence writes back and invalidates the whole L2 of the XCD (buffer_wbl2 / buffer_inv), and
+// with one per wave of every block the histogram pass ran 8 x slower (measured: 327 us instead of 40 us on 128 MiB).
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// All threads of the block call this after storing their counts with st_agent.  True (block-uniform) in the block that
+// arrives last of `count` at `ticket`; that block puts the ticket back to zero for the next call.  Order: every wave waits
+// until its write-through stores are acknowledged (vmcnt 0), the barrier collects the waves, THEN thread 0 moves the
+// ticket; the winner's loads are issued after the barrier that follows the atomic's return.
+__device__ __forceinline__ bool arrive_last(uint32_t* ticket, unsigned count, uint32_t* s_flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old + 1u == count;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+// Sum of `count` (<= kGroup) 256-bin count vectors at p (stride 256 words): bin tid & 255, the two halves of the
+// 512-thread block take alternate vectors.  Every load of a thread is issued before the first is used -- one memory round
+// trip, not count / 16 of them (the winner of a ticket is the only block still running: latency is all that matters).
+// The result is valid in threads 0..255.  s_tmp: 256 words of LDS.
+__device__ __forceinline__ uint32_t sum_counts(const uint32_t* p, unsigned count, uint32_t* s_tmp, unsigned tid)
+{
+    const unsigned bin = tid & 255u, half = tid >> 8;
+    p += bin;
+    uint32_t t[kGroup / 2];
+    // unconditional loads (vectors past the end re-read the last one and are not added): a load behind a branch would
+    // make the compiler wait for the loads in flight before it writes the zero of the other arm
+#pragma unroll
+    for (unsigned k = 0; k < kGroup / 2; ++k) {
+        const unsigned v = 2 * k + half;
+        t[k] = ld_agent(p + (size_t)(v < count ? v : count - 1) * 256);
+    }
+    uint32_t h = 0;
+#pragma unroll
+    for (unsigned k = 0; k < kGroup / 2; ++k) h += 2 * k + half < count ? t[k] : 0u;
+    if (half) s_tmp[bin] = h;
+    __syncthreads();
+    if (!half) h += s_tmp[bin];
+    return h;
+}
+
+// OpenCV histogram.cpp equalizeHist(): i0 = first non-zero bin; hist[i0]==total -> constant image maps to i0;
+// scale = 255.f/(total-hist[i0]); lut[i0]=0; lut[i>i0] = saturate_cast<uchar>(cvRound(float(sum_i)*scale)).
+// Called by exactly 256 threads (tid = bin, h = its count) that share s_scan (2 x 256 words) and s_i0; the block's other
+// threads have exited (exited waves no longer count at the barrier).
+__device__ __forceinline__ void finish_image(uint32_t h, unsigned tid, unsigned img, uint32_t* __restrict__ hist_out,
+                                             uint8_t* __restrict__ lut_out, uint32_t (*s_scan)[256], int* s_i0)
+{
+    if (hist_out) hist_out[(size_t)img * 256 + tid] = h;
+    if (!lut_out) return;
+    if (tid == 0) *s_i0 = 256;
+    s_scan[0][tid] = h;
+    __syncthreads();
+    if (h != 0) atomicMin(s_i0, (int)tid);
+    int cur = 0;                                             // Hillis-Steele inclusive scan over 256 bins
+#pragma unroll
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = s_scan[cur][tid];
+        if (tid >= (unsigned)off) v += s_scan[cur][tid - off];
+        s_scan[cur ^ 1][tid] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    const uint32_t incl = s_scan[cur][tid];                  // sum of bins 0..tid
+    const uint32_t total = s_scan[cur][255];
+    const int i0 = *s_i0;
+    uint32_t out = 0;
+    // The raw counts were overwritten by the scan; hist[i0] == incl(i0) because every bin below i0 is empty.
+    if (i0 < 256) {
+        const uint32_t hist_i0 = s_scan[cur][i0];
+        if (hist_i0 == total) {
+            out = (uint32_t)i0;                              // single-valued image: dst.setTo(i0)
+        } else if ((int)tid > i0) {
+            const float scale = __fdiv_rn(255.f, (float)(int)(total - hist_i0));
+            const float v = __builtin_rintf(__fmul_rn((float)(int)(incl - hist_i0), scale));
+            out = v < 0.f ? 0u : v > 255.f ? 255u : (uint32_t)v;
+        }
+    }
+    lut_out[(size_t)img * 256 + tid] = (uint8_t)out;
+}
+
+// End of a counting block (kThreads threads, all of them, after the barrier that follows the counting): fold the 32 copies
+// of the LDS histogram, store the block's counts and, in the last block of the image to get here, finish the image.
+__device__ __forceinline__ void hist_tail(uint32_t* s_hist, unsigned img, const HistTail& t)
+{
+    __shared__ uint32_t s_flag;
+    __shared__ int s_i0;
+    const unsigned tid = threadIdx.x, nparts = gridDim.x, b = blockIdx.x;
+    uint32_t h = 0;
+    // lane reads copy (j + tid) % 32 -> bank (j + tid) % 32: conflict-free
+    if (tid < 256) {
+#pragma unroll
+        for (int j = 0; j < kCopies; ++j) h += s_hist[(tid << 5) | ((j + tid) & 31u)];
+    }
+    if (!t.tickets) {                                        // hist_finish_kernel follows (the launch boundary publishes these)
+        if (tid < 256) t.partial[((size_t)img * nparts + b) * 256 + tid] = h;
+        return;
+    }
+    // level 1: groups of kGroup consecutive blocks; the last of a group to arrive sums the group
+    if (tid < 256) st_agent(&t.partial[((size_t)img * nparts + b) * 256 + tid], h);
+    const unsigned grp = b / kGroup, first = grp * kGroup;
+    const unsigned cnt = nparts - first < kGroup ? nparts - first : kGroup;
+    if (!arrive_last(t.tickets + kTicketImages + img * t.ngroups + grp, cnt, &s_flag)) return;
+    h = sum_counts(t.partial + ((size_t)img * nparts + first) * 256, cnt, s_hist, tid);
+    // level 2: the last group of the image to be summed sums the group sums
+    if (tid < 256) st_agent(&t.partial2[((size_t)img * t.ngroups + grp) * 256 + tid], h);
+    if (!arrive_last(t.tickets + img, t.ngroups, &s_flag)) return;
+    h = sum_counts(t.partial2 + (size_t)img * t.ngroups * 256, t.ngroups, s_hist, tid);
+    if (tid >= 256) return;
+    finish_image(h, tid, img, t.hist_out, t.lut_out, (uint32_t (*)[256])(s_hist + 256), &s_i0);
+}
+
 template <bool NT>
-__global__ __launch_bounds__(kThreads) void hist_partial_kernel(const uint8_t* __restrict__ src, HistGeom g,
-                                                                uint32_t* __restrict__ partial)
+__global__ __launch_bounds__(kThreads) void hist_partial_kernel(const uint8_t* __restrict__ src, HistGeom g, HistTail tail)
 {
     __shared__ uint32_t s_hist[256 * kCopies];
     const unsigned tid = threadIdx.x, copy = tid & 31u;
@@ -103,13 +252,7 @@ __global__ __launch_bounds__(kThreads) void hist_partial_kernel(const uint8_t* _
         }
     }
     __syncthreads();
-    // fold the 32 copies of bin `tid`; lane reads copy (j + tid) % 32 -> bank (j + tid) % 32: conflict-free
-    if (tid < 256) {
-        uint32_t sum = 0;
-#pragma unroll
-        for (int j = 0; j < kCopies; ++j) sum += s_hist[(tid << 5) | ((j + tid) & 31u)];
-        partial[((size_t)img * gridDim.x + blockIdx.x) * 256 + tid] = sum;
-    }
+    hist_tail(s_hist, img, tail);
 }
 
 
@@ -125,7 +268,7 @@ constexpr int kGUnit = kChunk * 2;     // pixels per block step: 2 x (3|4) x 16 
 
 template <int C, bool NT>
 __global__ __launch_bounds__(kThreads) void gray_hist_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ gray,
-                                                             GrayHistGeom g, uint32_t* __restrict__ partial)
+                                                             GrayHistGeom g, HistTail tail)
 {
     __shared__ uint32_t s_hist[256 * kCopies];
     __shared__ __attribute__((aligned(16))) uint8_t s_tr[C == 3 ? (kThreads / 64) * 3072 : 16];   // transpose_group3
@@ -188,17 +331,10 @@ __global__ __launch_bounds__(kThreads) void gray_hist_kernel(const uint8_t* __re
         }
     }
     __syncthreads();
-    if (tid < 256) {
-        uint32_t sum = 0;
-#pragma unroll
-        for (int j = 0; j < kCopies; ++j) sum += s_hist[(tid << 5) | ((j + tid) & 31u)];
-        partial[((size_t)img * gridDim.x + blockIdx.x) * 256 + tid] = sum;
-    }
+    hist_tail(s_hist, img, tail);
 }
 
-// One block per image: hist[bin] = sum over that image's partial blocks; optional equalization LUT.
-// OpenCV histogram.cpp equalizeHist(): i0 = first non-zero bin; hist[i0]==total -> constant image maps to i0;
-// scale = 255.f/(total-hist[i0]); lut[i0]=0; lut[i>i0] = saturate_cast<uchar>(cvRound(float(sum_i)*scale)).
+// One block per image: hist[bin] = sum over that image's partial blocks (or a given histogram); optional equalization LUT.
 constexpr int kFinishGroups = 4;                             // 4 x 256 threads share the partial-sum latency chain
 __global__ __launch_bounds__(256 * kFinishGroups) void hist_finish_kernel(const uint32_t* __restrict__ partial, unsigned nparts,
                                                                const uint32_t* __restrict__ hist_in,
@@ -230,38 +366,7 @@ __global__ __launch_bounds__(256 * kFinishGroups) void hist_finish_kernel(const 
         h = hist_in[(size_t)img * 256 + tid];
     }
     if (grp != 0) return;                                    // groups 1.. only helped with the partial sums
-    if (hist_out) hist_out[(size_t)img * 256 + tid] = h;
-    if (!lut_out) return;
-
-    if (tid == 0) s_i0 = 256;
-    s_scan[0][tid] = h;
-    __syncthreads();                                         // (exited waves no longer count at the barrier)
-    if (h != 0) atomicMin(&s_i0, (int)tid);
-    int cur = 0;                                             // Hillis-Steele inclusive scan over 256 bins
-#pragma unroll
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t v = s_scan[cur][tid];
-        if (tid >= (unsigned)off) v += s_scan[cur][tid - off];
-        s_scan[cur ^ 1][tid] = v;
-        cur ^= 1;
-        __syncthreads();
-    }
-    const uint32_t incl = s_scan[cur][tid];                  // sum of bins 0..tid
-    const uint32_t total = s_scan[cur][255];
-    const int i0 = s_i0;
-    uint32_t out = 0;
-    // The raw counts were overwritten by the scan; hist[i0] == incl(i0) because every bin below i0 is empty.
-    if (i0 < 256) {
-        const uint32_t hist_i0 = s_scan[cur][i0];
-        if (hist_i0 == total) {
-            out = (uint32_t)i0;                              // single-valued image: dst.setTo(i0)
-        } else if ((int)tid > i0) {
-            const float scale = __fdiv_rn(255.f, (float)(int)(total - hist_i0));
-            const float v = __builtin_rintf(__fmul_rn((float)(int)(incl - hist_i0), scale));
-            out = v < 0.f ? 0u : v > 255.f ? 255u : (uint32_t)v;
-        }
-    }
-    lut_out[(size_t)img * 256 + tid] = (uint8_t)out;
+    finish_image(h, tid, img, hist_out, lut_out, s_scan, &s_i0);
 }
 
 HistGeom make_geom(int h, int w, int64_t s_row, int64_t s_img)
@@ -292,17 +397,60 @@ unsigned blocks_per_image(int n, int h, int w, unsigned slots = 1024)
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+unsigned groups_of(unsigned nparts) { return ipx_div_up(nparts, kGroup); }
+
+// [tickets][partial counts][group sums][histograms][tables].  The tickets come first so that they are the same words for
+// every batch geometry a workspace is used with: they are zero between calls, everything behind them is overwritten.
 struct Workspace {
-    uint32_t* partial; uint32_t* hist; uint8_t* lut;
+    uint32_t* tickets; uint32_t* partial; uint32_t* partial2; uint32_t* hist; uint8_t* lut;
 };
 
 size_t workspace_layout(int n, int h, int w, Workspace* ws, uint8_t* base)
 {
-    const size_t p = align256((size_t)n * blocks_per_image(n, h, w) * 256 * sizeof(uint32_t));
+    const unsigned bpi = blocks_per_image(n, h, w);
+    const size_t p = align256((size_t)n * bpi * 256 * sizeof(uint32_t));
+    const size_t p2 = bpi >= kTicketMinBlocks ? align256((size_t)n * groups_of(bpi) * 256 * sizeof(uint32_t)) : 0;
     const size_t hs = align256((size_t)n * 256 * sizeof(uint32_t));
     const size_t ls = align256((size_t)n * 256);
-    if (ws) { ws->partial = (uint32_t*)base; ws->hist = (uint32_t*)(base + p); ws->lut = base + p + hs; }
-    return p + hs + ls;
+    if (ws) {
+        ws->tickets = (uint32_t*)base;
+        ws->partial = (uint32_t*)(base + kTicketBytes);
+        ws->partial2 = (uint32_t*)(base + kTicketBytes + p);
+        ws->hist = (uint32_t*)(base + kTicketBytes + p + p2);
+        ws->lut = base + kTicketBytes + p + p2 + hs;
+    }
+    return kTicketBytes + p + p2 + hs + ls;
+}
+
+// The in-kernel finish for a launch of n x nparts blocks, or tickets = null: the host launches hist_finish_kernel afterwards.
+// Which one is a measured choice (scripts/dev/histeq.py, same box, A/B): every block of a ticketed launch pays two serial
+// device-scope round trips at its end (write-through store acknowledged, then the atomic) and the winner two more per
+// level -- about 8 us whatever the geometry; the separate kernel costs its launch edge plus a sum whose length grows with
+// the blocks per image.  One image in 1024 blocks (a 128 MiB row partition): tickets 4 us faster; one 4K frame in 127
+// blocks: 2-3 us faster; 24 frames of 42 blocks each: tickets 2.7 us SLOWER.  Hence: tickets from 65 blocks per image up.
+HistTail make_tail(const Workspace& ws, int n, unsigned nparts, uint32_t* hist_out, uint8_t* lut_out)
+{
+    HistTail t;
+    t.partial = ws.partial; t.partial2 = ws.partial2; t.hist_out = hist_out; t.lut_out = lut_out;
+    t.ngroups = groups_of(nparts);
+    bool covered = nparts >= kTicketMinBlocks && t.ngroups <= kGroup && (unsigned)n <= kTicketImages &&
+                   (uint64_t)n * t.ngroups <= kTicketGroups;
+#ifdef IPX_DEV
+    static const bool env_off = [] { const char* e = getenv("IPX_HIST_NOTICKET"); return e && atoi(e) != 0; }();   // A/B: separate finish
+    if (env_off) covered = false;
+#endif
+    t.tickets = covered ? ws.tickets : nullptr;
+    return t;
+}
+
+// after a counting kernel launched with `t`: the separate finish where the in-kernel one was not possible
+int finish_if_needed(hipStream_t st, const HistTail& t, int n, unsigned nparts)
+{
+    if (t.tickets) return IPX_OK;
+    hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, st, t.partial, nparts,
+                       (const uint32_t*)nullptr, t.hist_out, t.lut_out);
+    IPX_LAUNCH_CHECK("hist_finish_kernel");
+    return IPX_OK;
 }
 
 int check_hist_args(const char* fn, const uint8_t* src, int n, int h, int w, int64_t s_row, int64_t s_img)
@@ -314,20 +462,21 @@ int check_hist_args(const char* fn, const uint8_t* src, int n, int h, int w, int
     return IPX_OK;
 }
 
-int launch_partial(hipStream_t st, const uint8_t* src, int n, int h, int w, int64_t s_row, int64_t s_img,
-                   uint32_t* partial, unsigned* nparts)
+// counting pass + finish: histograms to hist_out and/or tables to lut_out (either may be null)
+int launch_hist(hipStream_t st, const uint8_t* src, int n, int h, int w, int64_t s_row, int64_t s_img,
+                const Workspace& ws, uint32_t* hist_out, uint8_t* lut_out)
 {
     HistGeom g = make_geom(h, w, s_row, s_img);
     unsigned bpi = blocks_per_image(n, h, w);
     if (bpi > g.units_per_img) bpi = g.units_per_img;     // strided rows: fewer units than bytes/64K suggests
-    *nparts = bpi;
+    const HistTail t = make_tail(ws, n, bpi, hist_out, lut_out);
     // the histogram pass reads what the table pass re-reads right after: keep small batches in the Infinity Cache
     if (ipx_use_nt(2ull * (uint64_t)n * h * w, kNtHistThenLut))
-        hipLaunchKernelGGL(hist_partial_kernel<true>, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, partial);
+        hipLaunchKernelGGL(hist_partial_kernel<true>, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, t);
     else
-        hipLaunchKernelGGL(hist_partial_kernel<false>, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, partial);
+        hipLaunchKernelGGL(hist_partial_kernel<false>, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, t);
     IPX_LAUNCH_CHECK("hist_partial_kernel");
-    return IPX_OK;
+    return finish_if_needed(st, t, n, bpi);
 }
 
 // hist -> table -> table pass around a workspace laid out by workspace_layout (shared by the allocating and the
@@ -339,13 +488,39 @@ int equalize_with_workspace(hipStream_t st, const uint8_t* src, uint8_t* dst, in
     Workspace ws;
     workspace_layout(n, h, w, &ws, workspace);
     uint8_t* lut = lut_out_dev ? lut_out_dev : ws.lut;
-    unsigned nparts = 0;
-    if (int rc = launch_partial(st, src, n, h, w, s_row, s_img, ws.partial, &nparts)) return rc;
-    hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, st, ws.partial, nparts,
-                       (const uint32_t*)nullptr, hist_out_dev, lut);
-    IPX_LAUNCH_CHECK("hist_finish_kernel");
+    if (int rc = launch_hist(st, src, n, h, w, s_row, s_img, ws, hist_out_dev, lut)) return rc;
     // the table pass (default cache policy up to kNtHistThenLut bytes: what the histogram pass read is still in the Infinity Cache)
     return ipx_lut_dev_u8((void*)st, src, dst, n, h, w, 1, s_row, s_img, d_row, d_img, lut, 256);
+}
+
+// A workspace for one call: the caller's (tickets already zero: ipx_hist_workspace_init) or one from the stream-ordered
+// allocator, whose tickets are cleared here.
+int take_workspace(const char* fn, hipStream_t st, size_t need, void** workspace, size_t workspace_bytes, void** own)
+{
+    *own = nullptr;
+    if (*workspace) {
+        if (workspace_bytes < need) return ipx_fail(IPX_ERR_INVALID, "%s: workspace %zu < %zu bytes needed", fn, workspace_bytes, need);
+        if ((uintptr_t)*workspace & 3u) return ipx_fail(IPX_ERR_INVALID, "%s: workspace %p is not 4-byte aligned", fn, *workspace);
+        return IPX_OK;
+    }
+    IPX_HIP(hipMallocAsync(own, need, st));
+    hipError_t e = hipMemsetAsync(*own, 0, kTicketBytes, st);
+    if (e != hipSuccess) {
+        (void)hipFreeAsync(*own, st);
+        *own = nullptr;
+        return ipx_fail(IPX_ERR_HIP, "%s: hipMemsetAsync failed: %s", fn, hipGetErrorString(e));
+    }
+    *workspace = *own;
+    return IPX_OK;
+}
+
+int release_workspace(hipStream_t st, void* own, int rc)
+{
+    if (own) {
+        hipError_t e = hipFreeAsync(own, st);
+        if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
+    }
+    return rc;
 }
 
 // ---- scratch of the no-allocation entry point ---------------------------------------------------------------------
@@ -395,34 +570,30 @@ size_t ipx_hist_workspace_bytes(int n, int h, int w)
     return workspace_layout(n, h, w, nullptr, nullptr);
 }
 
+int ipx_hist_workspace_init(void* stream, void* workspace, size_t workspace_bytes)
+{
+    ipx_clear_error();
+    if (!workspace) return ipx_fail(IPX_ERR_INVALID, "ipx_hist_workspace_init: null workspace");
+    if ((uintptr_t)workspace & 3u) return ipx_fail(IPX_ERR_INVALID, "ipx_hist_workspace_init: workspace %p is not 4-byte aligned", workspace);
+    if (workspace_bytes < kTicketBytes)
+        return ipx_fail(IPX_ERR_INVALID, "ipx_hist_workspace_init: workspace %zu < %zu bytes (the smallest ipx_hist_workspace_bytes)",
+                        workspace_bytes, kTicketBytes);
+    IPX_HIP(hipMemsetAsync(workspace, 0, kTicketBytes, (hipStream_t)stream));
+    return IPX_OK;
+}
+
 int ipx_hist_u8(void* stream, const uint8_t* src, int n, int h, int w, int64_t src_row_stride, int64_t src_img_stride,
                 uint32_t* hist_dev, void* workspace, size_t workspace_bytes)
 {
     if (int rc = check_hist_args("ipx_hist_u8", src, n, h, w, src_row_stride, src_img_stride)) return rc;
     if (!hist_dev) return ipx_fail(IPX_ERR_INVALID, "ipx_hist_u8: null histogram output");
     hipStream_t st = (hipStream_t)stream;
-    const size_t need = workspace_layout(n, h, w, nullptr, nullptr);
     void* own = nullptr;
-    if (!workspace) {
-        IPX_HIP(hipMallocAsync(&own, need, st));
-        workspace = own;
-    } else if (workspace_bytes < need) {
-        return ipx_fail(IPX_ERR_INVALID, "ipx_hist_u8: workspace %zu < %zu bytes needed", workspace_bytes, need);
-    }
+    if (int rc = take_workspace("ipx_hist_u8", st, workspace_layout(n, h, w, nullptr, nullptr), &workspace, workspace_bytes, &own)) return rc;
     Workspace ws;
     workspace_layout(n, h, w, &ws, (uint8_t*)workspace);
-    unsigned nparts = 0;
-    int rc = launch_partial(st, src, n, h, w, src_row_stride, src_img_stride, ws.partial, &nparts);
-    if (rc == IPX_OK) {
-        hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, st, ws.partial, nparts,
-                           (const uint32_t*)nullptr, hist_dev, (uint8_t*)nullptr);
-        if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "launch of hist_finish_kernel failed");
-    }
-    if (own) {
-        hipError_t e = hipFreeAsync(own, st);
-        if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
-    }
-    return rc;
+    int rc = launch_hist(st, src, n, h, w, src_row_stride, src_img_stride, ws, hist_dev, nullptr);
+    return release_workspace(st, own, rc);
 }
 
 int ipx_equalize_lut_u8(void* stream, const uint32_t* hist_dev, int n, uint8_t* lut_dev)
@@ -444,21 +615,12 @@ int ipx_equalize_hist_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
                                       dst_row_stride, dst_img_stride)) return rc;
     if (int rc = check_hist_args("ipx_equalize_hist_u8", src, n, h, w, src_row_stride, src_img_stride)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t need = workspace_layout(n, h, w, nullptr, nullptr);
     void* own = nullptr;
-    if (!workspace) {
-        IPX_HIP(hipMallocAsync(&own, need, st));
-        workspace = own;
-    } else if (workspace_bytes < need) {
-        return ipx_fail(IPX_ERR_INVALID, "ipx_equalize_hist_u8: workspace %zu < %zu bytes needed", workspace_bytes, need);
-    }
+    if (int rc = take_workspace("ipx_equalize_hist_u8", st, workspace_layout(n, h, w, nullptr, nullptr), &workspace, workspace_bytes, &own))
+        return rc;
     int rc = equalize_with_workspace(st, src, dst, n, h, w, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride,
                                      hist_out_dev, lut_out_dev, (uint8_t*)workspace);
-    if (own) {
-        hipError_t e = hipFreeAsync(own, st);
-        if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
-    }
-    return rc;
+    return release_workspace(st, own, rc);
 }
 
 int ipx_equalize_hist_noalloc_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
@@ -475,8 +637,9 @@ int ipx_equalize_hist_noalloc_u8(void* stream, const uint8_t* src, uint8_t* dst,
                         "(use ipx_equalize_hist_u8 with a workspace)", fn, n, need, kScratchBytes);
     uint8_t* ws = nullptr;
     if (int rc = scratch_for_stream(fn, (hipStream_t)stream, &ws)) return rc;
-    // Nothing in the scratch has to start at zero: every partial count, histogram bin and table entry that is read
-    // is written first by this call's own kernels, so the previous call's contents are simply overwritten.
+    // The only words of the scratch that have to start at zero are the tickets at its head: the array is zero when the code
+    // object is loaded, and the block that wins a ticket puts it back to zero, so no call has to clear anything.  Every
+    // partial count, histogram bin and table entry that is read is written first by the same call's own kernels.
     return equalize_with_workspace((hipStream_t)stream, src, dst, n, h, w, src_row_stride, src_img_stride,
                                    dst_row_stride, dst_img_stride, hist_out_dev, lut_out_dev, ws);
 }
@@ -504,14 +667,8 @@ int ipx_bgr2gray_equalize_u8(void* stream, const uint8_t* src, uint8_t* gray, ui
     }
     if (int rc = check_hist_args(fn, gray, n, h, w, gray_row_stride, gray_img_stride)) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const size_t need = workspace_layout(n, h, w, nullptr, nullptr);
     void* own = nullptr;
-    if (!workspace) {
-        IPX_HIP(hipMallocAsync(&own, need, st));
-        workspace = own;
-    } else if (workspace_bytes < need) {
-        return ipx_fail(IPX_ERR_INVALID, "%s: workspace %zu < %zu bytes needed", fn, workspace_bytes, need);
-    }
+    if (int rc = take_workspace(fn, st, workspace_layout(n, h, w, nullptr, nullptr), &workspace, workspace_bytes, &own)) return rc;
     Workspace ws;
     workspace_layout(n, h, w, &ws, (uint8_t*)workspace);
     uint8_t* lut = lut_out_dev ? lut_out_dev : ws.lut;
@@ -525,23 +682,16 @@ int ipx_bgr2gray_equalize_u8(void* stream, const uint8_t* src, uint8_t* gray, ui
     unsigned bpi = blocks_per_image(n, h, w, 512);
     if (bpi > blocks_per_image(n, h, w)) bpi = blocks_per_image(n, h, w);
     if (bpi > g.units_per_img) bpi = g.units_per_img;
+    const HistTail t = make_tail(ws, n, bpi, hist_out_dev, lut);
     const bool nt = ipx_use_nt((uint64_t)n * h * w * src_channels, kNtGrayHist);
     auto k = src_channels == 3 ? (nt ? gray_hist_kernel<3, true> : gray_hist_kernel<3, false>)
                                : (nt ? gray_hist_kernel<4, true> : gray_hist_kernel<4, false>);
-    hipLaunchKernelGGL(k, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, gray, g, ws.partial);
+    hipLaunchKernelGGL(k, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, gray, g, t);
     int rc = hipGetLastError() == hipSuccess ? IPX_OK : ipx_fail(IPX_ERR_HIP, "%s: launch of gray_hist_kernel failed", fn);
-    if (rc == IPX_OK) {
-        hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, st, ws.partial, bpi,
-                           (const uint32_t*)nullptr, hist_out_dev, lut);
-        if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "%s: launch of hist_finish_kernel failed", fn);
-    }
+    if (rc == IPX_OK) rc = finish_if_needed(st, t, n, bpi);
     if (rc == IPX_OK && dst)
         rc = ipx_lut_dev_u8(stream, gray, dst, n, h, w, 1, gray_row_stride, gray_img_stride, dst_row_stride, dst_img_stride, lut, 256);
-    if (own) {
-        hipError_t e = hipFreeAsync(own, st);
-        if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "hipFreeAsync failed: %s", hipGetErrorString(e));
-    }
-    return rc;
+    return release_workspace(st, own, rc);
 }
 
 }  // extern "C"

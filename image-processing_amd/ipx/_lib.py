@@ -37,6 +37,7 @@ SIGNATURES = {
     "ipx_lut_multi_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i] + _STR + [_vp, _i64]),
     "ipx_bgr2gray_lut_u8": (_i, _IMG + [_i] + _STR + [_vp]),
     "ipx_hist_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ipx_hist_workspace_init": (_i, [_vp, _vp, _sz]),
     "ipx_hist_u8": (_i, [_vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _sz]),
     "ipx_equalize_lut_u8": (_i, [_vp, _vp, _i, _vp]),
     "ipx_equalize_hist_u8": (_i, _IMG + _STR + [_vp, _vp, _vp, _sz]),

@@ -173,10 +173,28 @@ def _gray(src: torch.Tensor) -> _Img:
     return s
 
 
+_ws_cache: dict = {}            # (device index, stream handle) -> initialised workspace tensor
+
+
 def _workspace(s: _Img) -> torch.Tensor:
-    """Scratch for the histogram kernels, from torch's caching allocator (stream-ordered, no hipMalloc per call)."""
-    nbytes = _lib.load().ipx_hist_workspace_bytes(s.n, s.h, s.w)
-    return torch.empty((nbytes,), dtype=torch.uint8, device=s.t.device)
+    """Scratch for the histogram kernels: one buffer per (device, stream), grown on demand and prepared once with
+    ipx_hist_workspace_init (the kernels keep its tickets at zero themselves, so there is no memset and no allocation per
+    call).  Calls on one stream are ordered, which is what sharing the buffer needs.  Under graph capture the buffer comes
+    from the capture's own pool and is initialised inside the graph."""
+    lib = _lib.load()
+    nbytes = lib.ipx_hist_workspace_bytes(s.n, s.h, s.w)
+    dev = s.t.device
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
+    ws = None if capturing else _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty((max(nbytes, 2 << 20),), dtype=torch.uint8, device=dev)
+        _lib.call("ipx_hist_workspace_init", _stream(), ws.data_ptr(), ws.numel())
+        if not capturing:
+            if len(_ws_cache) >= 64:                     # streams come and go: drop the lot rather than track them
+                _ws_cache.clear()
+            _ws_cache[key] = ws
+    return ws
 
 
 def hist(src: torch.Tensor) -> torch.Tensor:
@@ -244,7 +262,7 @@ def bgr2gray_equalize(src: torch.Tensor, return_aux: bool = False):
         raise ValueError("bgr2gray_equalize needs 3 (BGR) or 4 (BGRA) channels")
     with torch.cuda.device(s.t.device):
         gray, out = s.like(1), s.like(1)
-        ws = torch.empty((_lib.load().ipx_hist_workspace_bytes(s.n, s.h, s.w),), dtype=torch.uint8, device=s.t.device)
+        ws = _workspace(s)
         hst = lut = None
         if return_aux:
             hst = torch.empty((s.n, 256), dtype=torch.int32, device=s.t.device)
@@ -265,7 +283,7 @@ def bgr2gray_hist(src: torch.Tensor):
         raise ValueError("bgr2gray_hist needs 3 (BGR) or 4 (BGRA) channels")
     with torch.cuda.device(s.t.device):
         gray = s.like(1)
-        ws = torch.empty((_lib.load().ipx_hist_workspace_bytes(s.n, s.h, s.w),), dtype=torch.uint8, device=s.t.device)
+        ws = _workspace(s)
         hst = torch.empty((s.n, 256), dtype=torch.int32, device=s.t.device)
         lut = torch.empty((s.n, 256), dtype=torch.uint8, device=s.t.device)
         _lib.call("ipx_bgr2gray_equalize_u8", _stream(), s.ptr, gray.data_ptr(), None, s.n, s.h, s.w, s.c,

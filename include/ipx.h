@@ -97,10 +97,22 @@ int ipx_bgr2gray_lut_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, i
 
 /* ---- histogram ---------------------------------------------------------------------------- */
 
-/* Scratch bytes ipx_hist_u8 / ipx_equalize_hist_u8 need for a batch of this geometry (device memory,
- * 256-byte aligned, contents don't matter).  Pass such a buffer as `workspace`, or NULL to let the
- * call take it from the stream-ordered allocator (hipMallocAsync/hipFreeAsync on `stream`). */
+/* Scratch bytes ipx_hist_u8 / ipx_equalize_hist_u8 / ipx_bgr2gray_equalize_u8 need for a batch of this geometry (device
+ * memory, 256-byte aligned).  Pass such a buffer as `workspace`, or NULL to let the call take it from the
+ * stream-ordered allocator (hipMallocAsync/hipFreeAsync on `stream`).
+ * A workspace the CALLER passes must have been prepared ONCE, after it was allocated, with ipx_hist_workspace_init
+ * (below), on a stream ordered before its first use.  Its first bytes hold the tickets with which the last block of an
+ * image to finish counting recognises itself (it then sums the partial counts and builds the table in the same launch);
+ * they are zero between calls -- the block that wins a ticket puts it back -- so the same buffer serves any number of
+ * later calls of any geometry it is large enough for, with no memset per call.  Everything behind the tickets is scratch whose
+ * contents don't matter.  A workspace that was never initialised gives undefined histograms and tables.  Calls that share
+ * one workspace must not overlap in time (one stream, or ordered by events). */
 size_t ipx_hist_workspace_bytes(int n, int h, int w);
+
+/* Zeroes the tickets at the head of `workspace` (one hipMemsetAsync of 16.5 KiB on `stream`).  workspace_bytes: the size
+ * of the buffer, at least ipx_hist_workspace_bytes of the smallest batch it will serve.  No counterpart in the reference
+ * (cv2.equalizeHist owns its scratch). */
+int ipx_hist_workspace_init(void* stream, void* workspace, size_t workspace_bytes);
 
 /* 256-bin histogram of each image: hist_dev[i*256 + v] = #pixels of image i equal to v (uint32).
  * First half of cv2.equalizeHist (server.py:246); also the source of s.max() for the log transform
@@ -130,8 +142,9 @@ int ipx_equalize_hist_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
  * process ends; the call makes no hipMalloc / hipFree / allocating library call.  Limit: batches whose
  * ipx_hist_workspace_bytes(n, h, w) exceeds IPX_NOALLOC_SCRATCH_BYTES are rejected with IPX_ERR_UNSUPPORTED
  * (any batch of up to 256 images fits, whatever the image size).  All calls on one GPU share that GPU's array: calls that
- * overlap in time on one GPU (two streams, two threads) race -- serialise them.  Nothing in the array has to
- * start at zero (every word that is read is written first by the same call).  The array used is that of the GPU `stream`
+ * overlap in time on one GPU (two streams, two threads) race -- serialise them.  Only the tickets at the array's head have
+ * to start at zero: they do when the code object is loaded, and the kernel puts each one back to zero itself (every other
+ * word that is read is written first by the same call), so no call clears anything.  The array used is that of the GPU `stream`
  * belongs to (the current device for the null stream).  The FIRST call per GPU looks the array's address up
  * (hipGetSymbolAddress, which may load the code object): make one call outside a graph capture first; every later
  * call can be captured (tests/test_zz_no_alloc.py captures and replays one). */

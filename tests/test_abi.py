@@ -53,6 +53,11 @@ def test_argument_errors_are_reported_not_thrown():
     assert lib.ipx_bgr2gray_u8(None, 1, 1, 1, 4, 4, 3, 8, 48, 4, 16) == L.IPX_ERR_INVALID  # stride < row bytes
     with pytest.raises(L.IpxError):
         L.call("ipx_equalize_lut_u8", None, None, 1, None)
+    # a histogram workspace: null, misaligned, or shorter than its tickets
+    assert lib.ipx_hist_workspace_init(None, None, 1 << 20) == L.IPX_ERR_INVALID
+    assert lib.ipx_hist_workspace_init(None, 0x1001, 1 << 20) == L.IPX_ERR_INVALID
+    assert lib.ipx_hist_workspace_init(None, 0x1000, 1024) == L.IPX_ERR_INVALID
+    assert lib.ipx_hist_workspace_bytes(1, 16, 16) >= (4096 + 128) * 4
 
 
 def test_cpu_tensor_is_refused():

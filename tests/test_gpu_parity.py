@@ -109,6 +109,78 @@ def test_equalize_batch_each_image_own_table(dev):
         np.testing.assert_array_equal(out[i, :, :, 0], O.equalize_hist_u8(imgs[i, :, :, 0]))
 
 
+def test_hist_ticketed_finish_one_workspace_over_many_geometries(dev):
+    """For images cut into 65 or more blocks the last block to arrive sums the partial counts (two levels) and builds the
+    table inside the counting launch: tickets at the head of the workspace, zeroed ONCE by ipx_hist_workspace_init and put
+    back by the kernel.  One workspace is reused, without re-initialisation, over batches on both sides of that limit:
+    1, 22, 32, 64 blocks per image (separate finish kernel), 65 (two full groups and one of a single block), 138 and 163
+    (ragged last group), 1024 (32 x 32), several images with their own tickets, more images than tickets, then earlier
+    geometries again.  All through the C ABI: ipx_hist_u8, ipx_equalize_hist_u8, ipx_bgr2gray_equalize_u8, and the
+    NULL-workspace path."""
+    import ipx._lib as L
+    lib = L.load()
+    rng = np.random.default_rng(91)
+    geoms = [(1, 40, 50), (1, 700, 2048), (1, 2600, 4096), (3, 1024, 2048), (2, 3000, 3000), (1, 1024, 4096), (1, 1040, 4096),
+             (24, 300, 1000), (5000, 6, 9), (1, 8200, 8192), (7, 1100, 4096), (1, 40, 50), (1, 2600, 4096)]
+    big = max(lib.ipx_hist_workspace_bytes(*g) for g in geoms)
+    ws = torch.full((big,), 0xA5, dtype=torch.uint8, device=dev)          # garbage everywhere ...
+    L.call("ipx_hist_workspace_init", None, ws.data_ptr(), ws.numel())     # ... but the tickets
+    for rep, (n, h, w) in enumerate(geoms):
+        imgs = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+        if rep % 3 == 1:
+            imgs[0, : h // 2] = 7                                          # a heavy bin; i0 > 0 for some images
+            imgs[0] = np.maximum(imgs[0], 7)
+        t = dev_t(imgs, dev)
+        want_h = np.stack([np.bincount(imgs[i].ravel(), minlength=256) for i in range(n)])
+        want_l = np.stack([O.equalize_lut_from_hist(want_h[i]) for i in range(n)]) if n <= 64 else None
+        hst = torch.zeros((n, 256), dtype=torch.int32, device=dev)
+        L.call("ipx_hist_u8", None, t.data_ptr(), n, h, w, w, w * h, hst.data_ptr(), ws.data_ptr(), ws.numel())
+        np.testing.assert_array_equal(host(hst), want_h, err_msg=f"hist {n}x{h}x{w}")
+        out = torch.empty_like(t)
+        hst.zero_()
+        lut = torch.zeros((n, 256), dtype=torch.uint8, device=dev)
+        L.call("ipx_equalize_hist_u8", None, t.data_ptr(), out.data_ptr(), n, h, w, w, w * h, w, w * h,
+               hst.data_ptr(), lut.data_ptr(), ws.data_ptr(), ws.numel())
+        np.testing.assert_array_equal(host(hst), want_h, err_msg=f"equalize hist {n}x{h}x{w}")
+        if want_l is not None:
+            np.testing.assert_array_equal(host(lut), want_l, err_msg=f"table {n}x{h}x{w}")
+            got = host(out)
+            for i in range(n):
+                assert (got[i] == want_l[i][imgs[i]]).all(), f"pixels {n}x{h}x{w} image {i}"
+        # the same call with no workspace (stream-ordered allocation, tickets cleared by the call) agrees
+        out2, lut2 = torch.empty_like(t), torch.zeros_like(lut)
+        L.call("ipx_equalize_hist_u8", None, t.data_ptr(), out2.data_ptr(), n, h, w, w, w * h, w, w * h,
+               None, lut2.data_ptr(), None, 0)
+        assert torch.equal(lut, lut2) and torch.equal(out, out2)
+    # rows with a stride (units are cut per row), and the colour entry point on the same workspace
+    n, h, w, pitch = 2, 700, 1500, 1536
+    buf = rng.integers(0, 256, (n, h, pitch), dtype=np.uint8)
+    t = dev_t(buf, dev)
+    hst = torch.zeros((n, 256), dtype=torch.int32, device=dev)
+    L.call("ipx_hist_u8", None, t.data_ptr(), n, h, w, pitch, pitch * h, hst.data_ptr(), ws.data_ptr(), ws.numel())
+    np.testing.assert_array_equal(host(hst), np.stack([np.bincount(buf[i, :, :w].ravel(), minlength=256) for i in range(n)]))
+    for shape in ((1, 2160, 3840, 3), (4, 500, 1200, 3), (1, 9, 11, 4)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        n, h, w, c = shape
+        t = dev_t(img, dev)
+        gray = torch.empty((n, h, w), dtype=torch.uint8, device=dev)
+        eq = torch.empty_like(gray)
+        hst = torch.zeros((n, 256), dtype=torch.int32, device=dev)
+        L.call("ipx_bgr2gray_equalize_u8", None, t.data_ptr(), gray.data_ptr(), eq.data_ptr(), n, h, w, c, w * c, w * c * h,
+               w, w * h, w, w * h, hst.data_ptr(), None, ws.data_ptr(), ws.numel())
+        for i in range(n):
+            g = O.bgr2gray_u8(img[i])
+            np.testing.assert_array_equal(host(hst)[i], np.bincount(g.ravel(), minlength=256))
+            tab = O.equalize_lut_from_hist(np.bincount(g.ravel(), minlength=256))
+            assert (host(eq)[i] == tab[g]).all()
+    # the tickets are back at zero after all of that; everything behind them was scratch
+    assert int(ws[: (4096 + 128) * 4].view(torch.int32).abs().sum()) == 0
+    with pytest.raises(L.IpxError):
+        L.call("ipx_hist_workspace_init", None, None, 1 << 20)
+    with pytest.raises(L.IpxError):
+        L.call("ipx_hist_workspace_init", None, ws.data_ptr(), 1024)
+
+
 def test_equalize_lut_from_large_histograms(dev):
     """float32 scale / int->float rounding at 2^30 pixels: LUT kernel alone."""
     rng = np.random.default_rng(8)
