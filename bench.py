@@ -404,6 +404,32 @@ def main():
     for i in range(lat_steps):
         step_one(lat_events[i])
     torch.cuda.synchronize()
+    # the same one-image step captured once into a HIP graph and replayed (ipx.pipelines.GraphedStep): one enqueue per step
+    # instead of three calls through Python and ctypes; "forked" = the Gaussian on a second branch of the graph
+    import ipx.pipelines as pipelines
+    graph_events = {}
+    side = torch.cuda.Stream(device=dev)
+    for key, fn in (("step_graph", lambda x: pipelines.configs1_one_image(ops, x)),
+                    ("step_graph_forked", lambda x: pipelines.configs1_one_image(ops, x, side))):
+        gstep = pipelines.GraphedStep(fn, one)
+        for _ in range(5):
+            gstep()
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(lat_steps)]
+        for e in evs:
+            e[0].record()
+            gstep()
+            e[1].record()
+        torch.cuda.synchronize()
+        graph_events[key] = evs
+        if key == "step_graph":                              # a queue of single-frame requests: replays back to back
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(lat_steps):
+                gstep()
+            e1.record()
+            torch.cuda.synchronize()
+            graph_stream_us = e0.elapsed_time(e1) / lat_steps * 1e3
+        del gstep
     rank_ms = [dt / args.steps * 1e3]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -457,8 +483,16 @@ def main():
             latency_b1_us[name] = round(ts[len(ts) // 2] * 1e3, 1)
         ts = sorted(lat_events[i][0].elapsed_time(lat_events[i][3]) for i in range(lat_steps))
         latency_b1_us["step"] = round(ts[len(ts) // 2] * 1e3, 1)
+        for key, evs in graph_events.items():
+            ts = sorted(e[0].elapsed_time(e[1]) for e in evs)
+            latency_b1_us[key] = round(ts[len(ts) // 2] * 1e3, 1)
+        latency_b1_us["step_graph_queued"] = round(graph_stream_us, 1)
         latency_b1_us["note"] = ("median over 50 steps of ONE 3840x2160 RGB image per launch, HIP events around every op; "
-                                 "one image is 25 MB: launch + ramp dominate, not bandwidth")
+                                 "one image is 25 MB: launch + ramp dominate, not bandwidth.  step_graph: the same step "
+                                 "(same kernels, same pixels: tests/test_gpu_configs.py) captured into a HIP graph and "
+                                 "replayed, events around ONE replay on an idle GPU (includes the graph's launch latency); "
+                                 "step_graph_forked: the Gaussian as a parallel branch; step_graph_queued: 50 replays "
+                                 "enqueued back to back, time per step (a queue of single-frame requests)")
         if args.ops_table:
             gray = ops.bgr2gray(bgr)
             for _ in range(40):        # the one-image launches above leave the chip idle: its first measurements afterwards read

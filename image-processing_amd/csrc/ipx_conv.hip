@@ -1465,6 +1465,15 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
             s2 = (s2 + gran - 1) / gran * gran;
             if (s2 > seg && s2 <= hi) seg = s2;
         }
+        // a launch that cannot fill half the slots (ONE frame per request, a few small ones): a lone wave walks its strip
+        // row by row with a handful of loads in flight, so the launch lasts as long as its longest walk, whatever the
+        // bandwidth.  Shorter segments, down to one unrolled step, until there are ~2048 waves; the extra halo rows
+        // (6 rows read per 4 written at r = 1) hit in L2.  One 4K gray frame, Sobel: 9.3 -> 7.4 us (scripts/dev/onetune.py)
+        if (waves < slots / 2) {
+            int s2 = (int)(strips * h / (slots / 2)) / gran * gran;
+            if (s2 < gran) s2 = gran;
+            if (s2 < seg) seg = s2;
+        }
     }
     if (seg > h) seg = h;
     g.seg_rows = seg;

@@ -379,16 +379,20 @@ HistGeom make_geom(int h, int w, int64_t s_row, int64_t s_img)
     return g;
 }
 
-// blocks per image: enough blocks to fill the chip (LDS admits 4-5 blocks per CU), but at least
-// 64 KiB of pixels per block so that zeroing/folding the 32 KiB LDS histogram stays in the noise.
+// blocks per image: enough blocks to fill the chip (LDS admits 4-5 blocks per CU) in one round
 unsigned blocks_per_image(int n, int h, int w, unsigned slots = 1024)
 {
     const uint64_t bytes = (uint64_t)h * (uint64_t)w;
-    uint64_t by_work = (bytes + 65535) / 65536;
+    // at least 64 KiB of pixels per block, so that zeroing and folding the 32 KiB LDS histogram stays in the noise -- unless
+    // that leaves CUs without a block: one 4K frame is 127 such blocks on 256 CUs; 32 KiB each: 20.6 -> 16.0 us for
+    // cvtColor + histogram of one frame (scripts/dev/onetune.py)
+    uint64_t grain = (uint64_t)n * bytes / 256 / 16384 * 16384;
+    grain = grain < 16384 ? 16384 : grain > 65536 ? 65536 : grain;
 #ifdef IPX_DEV
-    static const int env_slots = [] { const char* e = getenv("IPX_HIST_SLOTS"); return e ? atoi(e) : 0; }();   // read once
-    if (env_slots > 0) slots = (unsigned)env_slots;
+    if (const char* e = getenv("IPX_HIST_SLOTS")) { if (atoi(e) > 0) slots = (unsigned)atoi(e); }     // (re-read per call: sweeps)
+    if (const char* e = getenv("IPX_HIST_GRAIN")) { if (atoi(e) > 0) grain = (uint64_t)atoi(e); }
 #endif
+    uint64_t by_work = (bytes + grain - 1) / grain;
     uint64_t by_chip = slots / (uint64_t)n;                      // 256 CUs x resident blocks per CU: ONE round (rounding up
                                                                  // put e.g. 24 images x 22 blocks = 528 blocks on 512 slots)
     uint64_t b = by_work < by_chip ? by_work : by_chip;

@@ -82,3 +82,69 @@ def configs1_step(ops, bgr):
     gray, _, lut = ops.bgr2gray_hist(bgr)
     sb = ops.sobel(gray)
     return g5, ops.apply_lut_dev(gray, lut), sb
+
+
+def configs1_one_image(ops, bgr, side_stream=None):
+    """BASELINE.json configs[1] taken literally -- ONE image per launch, what three single /api/process requests do: the
+    5x5 Gaussian (server.py:428), the fused cvtColor + equalizeHist call (:245-246) and Sobel on the gray image.  Returns
+    (gaussian, gray, equalized, sobel).  With `side_stream` the Gaussian, which shares nothing with the other two but
+    its input, is enqueued there (forked from and joined to the current stream): one frame leaves the chip mostly idle
+    during each kernel's ramp and tail, and under graph capture the fork becomes two branches that overlap."""
+    import torch
+    if side_stream is None:
+        g5 = ops.gaussian_blur(bgr, 5)
+    else:
+        cur = torch.cuda.current_stream()
+        side_stream.wait_stream(cur)
+        with torch.cuda.stream(side_stream):
+            g5 = ops.gaussian_blur(bgr, 5)
+    gray, eq = ops.bgr2gray_equalize(bgr)
+    sb = ops.sobel(gray)
+    if side_stream is not None:
+        torch.cuda.current_stream().wait_stream(side_stream)
+    return g5, gray, eq, sb
+
+
+class GraphedStep:
+    """A fixed sequence of ipx.ops calls on inputs of fixed shapes, captured ONCE into a HIP graph and replayed per request
+    (VERDICT r02 item 5).  One 4K frame keeps the GPU busy for ~10-20 us per kernel, the same order as the time the host
+    needs to enqueue a launch through Python and ctypes; a replay enqueues the whole step with one call.
+
+        step = GraphedStep(lambda x: pipelines.configs1_one_image(ops, x), frame)
+        outs = step(new_frame)            # copies new_frame into step.inputs[0], replays; outs are the SAME tensors each time
+        step.inputs[0].copy_(pinned, non_blocking=True); outs = step()      # or upload straight into the static input
+
+    Inside the capture every output and temporary comes from the graph's private memory pool and the histogram workspace is
+    the capture stream's cached one, initialised during the eager warm-up on that stream -- the graph holds kernel launches
+    only.  Outputs are overwritten by the next replay: consume (or copy) them first, on the stream the replay ran on."""
+
+    def __init__(self, fn, *example, warmup: int = 3):
+        import torch
+        if not example or not all(isinstance(e, torch.Tensor) and e.is_cuda for e in example):
+            raise ValueError("GraphedStep: CUDA tensors expected as example inputs")
+        self.fn = fn
+        dev = example[0].device
+        self.inputs = [e.clone() for e in example]
+        self.stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(1, warmup)):            # loads code objects, fills the per-stream workspace cache, warms the allocator
+                fn(*self.inputs)
+        self.stream.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.outputs = fn(*self.inputs)
+        cur.wait_stream(self.stream)
+
+    def __call__(self, *xs):
+        if xs:
+            if len(xs) != len(self.inputs):
+                raise ValueError(f"GraphedStep: {len(self.inputs)} inputs expected, got {len(xs)}")
+            for dst, x in zip(self.inputs, xs):
+                if x is not dst:
+                    if x.shape != dst.shape or x.dtype != dst.dtype:
+                        raise ValueError(f"GraphedStep was captured for {tuple(dst.shape)} {dst.dtype}, got {tuple(x.shape)} {x.dtype}")
+                    dst.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.outputs

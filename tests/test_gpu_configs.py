@@ -70,6 +70,34 @@ def test_configs1_single_4k_rgb_gaussian_sobel_equalize(dev):
     np.testing.assert_array_equal(ops.sobel(t).cpu().numpy(), CO.sobel_u8(bgr))
 
 
+def test_configs1_one_image_step_replayed_from_a_graph(dev):
+    """ipx.pipelines.GraphedStep: the one-image configs[1] step captured once into a HIP graph, linear and with the Gaussian
+    as a forked branch; replays on NEW frames give the pixels of the eager calls and of the C oracle, the histogram
+    workspace's tickets survive replay after replay, and a frame of another shape is refused."""
+    frames = _frames(4, 2160, 3840, 12)
+    frames[2][:] = 77                                                   # a constant frame: the single-valued table
+    side = torch.cuda.Stream(device=dev)
+    for fork in (None, side):
+        step = P.GraphedStep(lambda x: P.configs1_one_image(ops, x, fork), torch.from_numpy(frames[0]).to(dev))
+        for k in (1, 2, 3, 0, 1):
+            t = torch.from_numpy(frames[k]).to(dev)
+            g5, gray, eq, sb = [o.clone() for o in step(t)]
+            e5, egray, eeq, esb = P.configs1_one_image(ops, t)
+            assert torch.equal(g5, e5) and torch.equal(gray, egray) and torch.equal(eq, eeq) and torch.equal(sb, esb), f"frame {k}"
+        want_gray = CO.bgr2gray_u8(frames[1])
+        np.testing.assert_array_equal(g5.cpu().numpy(), CO.gaussian_blur_u8(frames[1], 5))
+        np.testing.assert_array_equal(gray.cpu().numpy(), want_gray)
+        np.testing.assert_array_equal(eq.cpu().numpy(), CO.equalize_hist_u8(want_gray))
+        np.testing.assert_array_equal(sb.cpu().numpy(), CO.sobel_u8(want_gray))
+        with pytest.raises(ValueError):
+            step(torch.zeros((1080, 1920, 3), dtype=torch.uint8, device=dev))
+        # uploading straight into the static input and replaying without arguments is the zero-copy form
+        step.inputs[0].copy_(torch.from_numpy(frames[3]))
+        out = step()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out[2].cpu().numpy(), CO.equalize_hist_u8(CO.bgr2gray_u8(frames[3])))
+
+
 def test_configs2_full_pipeline_1080p_batch(dev):
     n, h, w = 8, 1080, 1920
     frames = _frames(n, h, w, 1002)
