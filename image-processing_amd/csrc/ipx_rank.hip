@@ -11,6 +11,7 @@
 //                                 host from these two.
 // OpenCV is absent from this image: these restate its published definitions (parity unpinned).
 #include "ipx_common.h"
+#include <stdlib.h>
 
 int ipx_median3_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
                        int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img);
@@ -25,6 +26,8 @@ int ipx_median11_walker(hipStream_t st, const uint8_t* src, uint8_t* dst, int n,
 int ipx_morph_small(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
                     int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, int dilate,
                     const uint32_t* row_bits, int se_rows, int se_cols);
+int ipx_median_rows(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int h, int w,
+                    int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, int k);
 
 namespace {
 
@@ -377,6 +380,14 @@ int ipx_median_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, in
         }
         IPX_LAUNCH_CHECK("median_small_kernel");
         return IPX_OK;
+    }
+    if (k >= 13
+#ifdef IPX_DEV
+        && !getenv("IPX_MEDIAN_COLHIST")                              // A/B switch of development builds
+#endif
+    ) {                                                               // a lane per row, per-lane window histograms (ipx_medianrow.hip)
+        const int rc = ipx_median_rows((hipStream_t)stream, src, dst, n, h, w, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride, k);
+        return rc < 0 ? rc : IPX_OK;
     }
     // sliding histograms: a wave per 64-column strip and row band; bands sized to give the chip a few thousand waves,
     // but never much shorter than the k rows it costs to set a band's histograms up
