@@ -520,7 +520,8 @@ def main():
                 ("median_7", "median7_kernel", 2, lambda: ops.median_blur(gray, 7)),
                 ("median_9", "median9_kernel", 2, lambda: ops.median_blur(gray, 9)),
                 ("median_11", "median11_kernel", 2, lambda: ops.median_blur(gray, 11)),
-                ("median_31", "median_hist_kernel", 2, lambda: ops.median_blur(gray, 31)),
+                ("median_15", "median_row_kernel<15>", 2, lambda: ops.median_blur(gray, 15)),
+                ("median_31", "median_row_kernel<31>", 2, lambda: ops.median_blur(gray, 31)),
             ]:
                 kernels[name] = row(kern, bpp, time_op(fn), "20 back-to-back launches between two HIP events")
         dom_name = max(STEP_OPS, key=lambda o: kernels[o[0]]["us_per_launch"])[0]

@@ -110,26 +110,64 @@ __global__ __launch_bounds__(64) void median_row_kernel(const uint8_t* __restric
 #pragma unroll
         for (int i = 0; i + 1 < C::kWords; ++i) wv[i] = __builtin_amdgcn_alignbit(d[i + 1], d[i], sh);
     };
+    // One update per window row: bit fields straight out of the packed column dwords (v_bfe_u32), address = field << 8 | lane
+    // (v_lshl_add_u32), increment = part * 0xffff + 1 (v_mad_u32_u24): 6 vector instructions and 2 LDS atomics per pixel
+    // value with 16-bit counters, 7 with 8-bit ones.  Written as instructions because the compiler turns the bit-field
+    // extracts back into shift / and / compare / select sequences (9 per value).
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    // (the LDS address of the lane's column of counters, as a number: the field << 8 is added to it by the same instruction,
+    // and the atomics take the sum as it is -- through a generic pointer every address would cost one more add)
+    const uint32_t lane4 = (uint32_t)(uintptr_t)(lds_u32*)lds + (uint32_t)lane * 4u;
+    const uint32_t k_ffff = 0xffffu;
     auto bump = [&](const uint32_t (&wv)[C::kOut], bool add) {
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const uint32_t v = (wv[j >> 2] >> (8 * (j & 3))) & 255u;
-            const uint32_t inc = 1u << ((v >> C::kShift) * (uint32_t)C::kBits);
-            uint32_t* f = fine + ((v & ((1u << C::kShift) - 1u)) << 6);
-            uint32_t* c = coarse + (((v >> 4) & (uint32_t)(C::kCoarseRows - 1)) << 6);
-            if (add) { atomicAdd(f, inc); atomicAdd(c, inc); }
-            else { atomicSub(f, inc); atomicSub(c, inc); }
+            const uint32_t word = wv[j >> 2];
+            constexpr int kCoarseBits = C::kWide ? 3 : 2;
+            uint32_t lo, part, cb, fo, co, inc;
+            asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(lo) : "v"(word), "n"(8 * (j & 3)), "n"(C::kShift));
+            asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(part) : "v"(word), "n"(8 * (j & 3) + C::kShift), "n"(8 - C::kShift));
+            asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(cb) : "v"(word), "n"(8 * (j & 3) + 4), "n"(kCoarseBits));
+            asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(fo) : "v"(lo), "v"(lane4));
+            asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(co) : "v"(cb), "v"(lane4));
+            if (C::kWide) {
+                asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc) : "v"(part), "v"(k_ffff));
+            } else {
+                uint32_t p8;
+                asm("v_lshlrev_b32 %0, 3, %1" : "=v"(p8) : "v"(part));
+                asm("v_lshlrev_b32 %0, %1, 1" : "=v"(inc) : "v"(p8));
+            }
+            lds_u32* f = (lds_u32*)(uintptr_t)fo;
+            lds_u32* c = (lds_u32*)(uintptr_t)co + C::kFineRows * 64;
+#ifdef IPX_MEDIAN_AB     // compile-time timing experiments (-DIPX_MEDIAN_AB=n, wrong pixels): 2 no coarse atomics, 16 no fine atomics,
+                         // 32 atomics on one fixed address (no address arithmetic), 64 address arithmetic only.  24 x 4K, k = 31, 7.2 ms:
+                         // atomics 2.5 ms + their address arithmetic 3.3 ms + column reads, rank search and stores 2.0 ms; the
+                         // three ADD UP (a wave's LDS and vector instructions issue in order, one wave per SIMD at 17+ taps)
+            constexpr bool with_coarse = !(IPX_MEDIAN_AB & 2), with_fine = !(IPX_MEDIAN_AB & 16);
+            if (IPX_MEDIAN_AB & 32) { f = (lds_u32*)(uintptr_t)lane4; c = f + 64; inc = 1u; }
+            if (IPX_MEDIAN_AB & 64) { asm volatile("" :: "v"(fo), "v"(co), "v"(inc)); continue; }
+#else
+            constexpr bool with_coarse = true, with_fine = true;
+#endif
+            if (add) {
+                if (with_fine) __hip_atomic_fetch_add(f, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (with_coarse) __hip_atomic_fetch_add(c, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                if (with_fine) __hip_atomic_fetch_sub(f, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (with_coarse) __hip_atomic_fetch_sub(c, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     };
     // smallest value whose cumulative count reaches `need`: the part (values 64 p .. / 128 p ..), then the coarse bin inside
-    // it, then the value inside the coarse bin
+    // it, then the value inside the coarse bin.  Prefix sums run on the packed dwords (no counter of a prefix exceeds k*k, so
+    // nothing carries between the parts); only the wanted part is pulled out of each.
     auto rank = [&]() -> uint32_t {
-        uint32_t cd[C::kCoarseRows];
+        uint32_t cp[C::kCoarseRows];
 #pragma unroll
-        for (int i = 0; i < C::kCoarseRows; ++i) cd[i] = coarse[i << 6];
-        uint32_t tot = 0;                                               // per part: the counters of a dword never carry (<= k*k)
+        for (int i = 0; i < C::kCoarseRows; ++i) cp[i] = coarse[i << 6];
 #pragma unroll
-        for (int i = 0; i < C::kCoarseRows; ++i) tot += cd[i];
+        for (int i = 1; i < C::kCoarseRows; ++i) cp[i] += cp[i - 1];
+        const uint32_t tot = cp[C::kCoarseRows - 1];
         constexpr uint32_t kMask = (1u << C::kBits) - 1u;
         uint32_t part = 0, below = 0, run = 0;
 #pragma unroll
@@ -140,27 +178,26 @@ __global__ __launch_bounds__(64) void median_row_kernel(const uint8_t* __restric
             below = lt ? run : below;
         }
         const uint32_t psh = part * (uint32_t)C::kBits;
-        uint32_t idx = 0;
-        run = below;
+        uint32_t want = (uint32_t)need - below;                         // rank inside the part
+        uint32_t idx = 0, under = 0;
 #pragma unroll
         for (int i = 0; i + 1 < C::kCoarseRows; ++i) {
-            run += (cd[i] >> psh) & kMask;
-            const bool lt = run < (uint32_t)need;
+            const uint32_t e = __builtin_amdgcn_ubfe(cp[i], psh, C::kBits);
+            const bool lt = e < want;
             idx += lt ? 1u : 0u;
-            below = lt ? run : below;
+            under = lt ? e : under;
         }
+        want -= under;                                                  // rank inside the coarse bin
         // coarse bin = part * kCoarseRows + idx; its 16 values live in fine dwords 16 idx .. 16 idx + 15, same part
         const uint32_t* f = fine + (idx << 10);
-        uint32_t fd[16];
+        uint32_t fp[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) fd[t] = f[t << 6];
+        for (int t = 0; t < 16; ++t) fp[t] = f[t << 6];
+#pragma unroll
+        for (int t = 1; t < 15; ++t) fp[t] += fp[t - 1];
         uint32_t low = 0;
-        run = below;
 #pragma unroll
-        for (int t = 0; t < 15; ++t) {
-            run += (fd[t] >> psh) & kMask;
-            low += run < (uint32_t)need ? 1u : 0u;
-        }
+        for (int t = 0; t < 15; ++t) low += __builtin_amdgcn_ubfe(fp[t], psh, C::kBits) < want ? 1u : 0u;
         return (part << C::kShift) + (idx << 4) + low;
     };
 

@@ -672,6 +672,31 @@ def test_median_many_strips_and_bands(dev, k):
     np.testing.assert_array_equal(host(ops.median_blur(dev_t(wide, dev), k)), O.median_blur_u8(wide, k))
 
 
+@pytest.mark.parametrize("k", list(range(13, 32, 2)))
+def test_median_per_row_window_histograms_every_k(dev, k):
+    """13..31 taps (one kernel instance each, ipx_medianrow.hip): a lane per row, packed 8-bit (13, 15 taps) / 16-bit counters.
+    Constant images (one counter takes all k*k samples: 225 of 255, 961 of 65535), two levels split near the rank (the
+    answer flips between parts of the packed dwords), values on both sides of every part boundary (63|64, 127|128,
+    191|192), several 64-row bands with a ragged last one, several column segments, images smaller than the window and
+    narrower than one staging chunk, a strided batch with an unaligned base."""
+    rng = np.random.default_rng(100 + k)
+    cases = [np.full((70, 140), 255, np.uint8), np.full((66, 40), 0, np.uint8), np.full((5, 7), 191, np.uint8),
+             np.where(rng.random((90, 300)) < 0.5, 0, 255).astype(np.uint8),
+             rng.choice(np.array([63, 64, 127, 128, 191, 192], np.uint8), (130, 200)),
+             rng.integers(0, 256, (131, 517), dtype=np.uint8), rng.integers(0, 256, (3, 300), dtype=np.uint8),
+             rng.integers(0, 256, (200, 9), dtype=np.uint8), (rng.integers(0, 4, (64, 256)) * 85).astype(np.uint8)]
+    yy, xx = np.mgrid[0:100, 0:280]
+    cases.append(((xx * 5 + yy * 3) % 256).astype(np.uint8))
+    cases.append(np.where(xx < 140, 10, 240).astype(np.uint8))          # a vertical edge: every row's median jumps at the same x
+    for img in cases:
+        np.testing.assert_array_equal(host(ops.median_blur(dev_t(img, dev), k)), O.median_blur_u8(img, k), err_msg=str(img.shape))
+    big = rng.integers(0, 256, (3, 90, 420), dtype=np.uint8)
+    view = dev_t(big, dev)[:, 3:80, 5:5 + 403].unsqueeze(-1)
+    got = host(ops.median_blur(view, k))
+    for i in range(3):
+        np.testing.assert_array_equal(got[i, :, :, 0], O.median_blur_u8(np.ascontiguousarray(big[i, 3:80, 5:408]), k))
+
+
 @pytest.mark.parametrize("shape", [(1, 1), (4, 9), (33, 70), (64, 97)])
 @pytest.mark.parametrize("m", [1, 3, 5, 7, 15, 31])
 def test_morphology(dev, shape, m):
