@@ -53,6 +53,9 @@ SIGNATURES = {
     "ipx_pairwise_sum_lut_f32": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "ipx_median_blur_u8": (_i, _IMG + _STR + [_i]),
     "ipx_morph_u8": (_i, _IMG + _STR + [_i, _vp, _i, _i]),
+    "ipx_base64_encode_u8": (_i, [_vp, _vp, _i64, _vp]),
+    "ipx_png_unfilter_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ipx_png_unfilter_u8": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 _lib = None

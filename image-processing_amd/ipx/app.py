@@ -50,6 +50,7 @@ class GpuBackend:
         """Stage arrays to the device, run fn(ops, *tensors) on this thread's stream, bring results back."""
         torch = self.torch
         with torch.cuda.device(self.device), torch.cuda.stream(self._stream()):
+            self._tls.png_status = []
             ts = [self._upload(a, i) for i, a in enumerate(arrays)]
             out = fn(self.ops, *ts)
             outs = out if isinstance(out, tuple) else (out,)
@@ -57,6 +58,10 @@ class GpuBackend:
             if getattr(self._tls, "upload_pending", False):            # the pinned upload buffers are reused by the next call
                 torch.cuda.current_stream().synchronize()
                 self._tls.upload_pending = False
+            bad = any(int(st.item()) != 0 for st in self._tls.png_status)   # (the stream is idle by now)
+            self._tls.png_status = []
+        if bad:                                                        # never seen: the GPU reconstruction gave up; Pillow's pixels
+            return self.run(fn, *[a.array() if isinstance(a, codec.LazyPng) else a for a in arrays])
         return host if isinstance(out, tuple) else host[0]
 
     def _upload(self, a, slot: int):
@@ -65,7 +70,11 @@ class GpuBackend:
         buffer is a host memcpy; the H2D copy is asynchronous on this thread's stream and ordered before the next use of
         the buffer by the synchronisation every request ends with (`_download`)."""
         torch = self.torch
-        a = np.ascontiguousarray(a)
+        lazy = a if isinstance(a, codec.LazyPng) else None
+        if lazy is not None:                                           # inflated PNG scan lines: the GPU un-filters them
+            a = np.frombuffer(lazy.raw, np.uint8)
+        else:
+            a = np.ascontiguousarray(a)
         if a.size == 0 or a.dtype != np.uint8:
             return torch.from_numpy(a).to(self.device)
         bufs = getattr(self._tls, "pinned_up", None)
@@ -78,7 +87,32 @@ class GpuBackend:
         view.numpy()[...] = a
         t = view.to(self.device, non_blocking=True)
         self._tls.upload_pending = True
+        if lazy is not None:
+            t, status = self.ops.png_unfilter(t, lazy.h, lazy.w, lazy.channels)
+            self._tls.png_status.append(status)
+            t = t.view(lazy.shape)
         return t
+
+    def b64encode(self, data: bytes) -> str:
+        """base64.b64encode(data).decode("ascii") (server.py:536-537) on the GPU: binascii holds the GIL for 40 ms per 4K colour
+        PNG; this is two pinned copies, one kernel and one pass that builds the str.  Small inputs stay on the host."""
+        n = len(data)
+        if n < (1 << 18):
+            import base64
+            return base64.b64encode(data).decode("ascii")
+        torch = self.torch
+        with torch.cuda.device(self.device), torch.cuda.stream(self._stream()):
+            bufs = getattr(self._tls, "pinned_b64", None)
+            m = 4 * ((n + 2) // 3)
+            if bufs is None or bufs[0].numel() < n:
+                bufs = self._tls.pinned_b64 = (torch.empty(max(n, 1 << 22), dtype=torch.uint8).pin_memory(),
+                                               torch.empty(4 * ((max(n, 1 << 22) + 2) // 3), dtype=torch.uint8).pin_memory())
+            src, dst = bufs
+            src[:n].numpy()[...] = np.frombuffer(data, np.uint8)
+            out = self.ops.base64_encode(src[:n].to(self.device, non_blocking=True))
+            dst[:m].copy_(out, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return str(memoryview(dst[:m].numpy()), "ascii")
 
     def _download(self, t):
         """Device tensor -> numpy through this thread's persistent pinned buffer: a pageable D2H copy of a 4K colour
@@ -97,6 +131,11 @@ class GpuBackend:
         return np.array(view.numpy())                                  # the buffer is reused by the next call
 
 
+def data_url(backend, img, order: str = "bgr") -> str:
+    """codec.to_data_url_png with the backend's base64 (GPU) when it has one; test backends fall back to the host's."""
+    return codec.to_data_url_png(img, order, b64=getattr(backend, "b64encode", None))
+
+
 def to_bgr(t):
     """RGB(A) tensor as decoded -> BGR(A), on the device the tensor lives on (the host copy this replaces costs more
     than the whole GPU side of a request)."""
@@ -108,11 +147,12 @@ def to_bgr(t):
 
 def ensure_gray_uint8(backend, img_bytes: bytes) -> np.ndarray:
     """server.py:492-531: decode, drop alpha, BGR->gray (GPU), 16-bit >> 8."""
-    return gray_from_decoded(backend, codec.decode_unchanged(img_bytes, "rgb"))
+    return gray_from_decoded(backend, codec.decode_lazy(img_bytes))
 
 
-def gray_from_decoded(backend, img: np.ndarray) -> np.ndarray:
-    """The part of ensure_gray_uint8 after the decode (`img` in RGB(A) order as decode_unchanged(..., "rgb") returns it)."""
+def gray_from_decoded(backend, img):
+    """The part of ensure_gray_uint8 after the decode (`img` in RGB(A) order as decode_unchanged(..., "rgb") or
+    decode_lazy returns it; a gray LazyPng passes through and is reconstructed when it is uploaded)."""
     if img.ndim == 3:
         img = backend.run(lambda ops, t: ops.bgr2gray(to_bgr(t)), img)  # 3 or 4 channels; alpha dropped
     if img.dtype == np.uint16:
@@ -171,11 +211,11 @@ def create_app(backend=None) -> Flask:
             params = {"method": method, "kernel": kernel,
                       "histogram": {"extreme_ratio": round(st["extreme_ratio"], 4), "variance": round(st["variance"], 2),
                                     "cv": round(st["cv"], 4), "suggested_method": st["suggested_method"]}}
-            return {"dataURL": codec.to_data_url_png(img_denoised), "message": f"Manual denoise: {method}",
+            return {"dataURL": data_url(b, img_denoised), "message": f"Manual denoise: {method}",
                             "params": params}, 200
 
         if mode == "histogram_eq":                                  # server.py:243-248
-            img = codec.decode_unchanged(data, "rgb")
+            img = codec.decode_lazy(data)
             if img.ndim == 3:                                        # colour: gray + histogram in one pass
                 img_eq = b.run(lambda ops, t: ops.bgr2gray_equalize(to_bgr(t))[1], img)
             else:
@@ -183,10 +223,10 @@ def create_app(backend=None) -> Flask:
                     img = (img >> 8).astype(np.uint8)
                 img_eq = b.run(lambda ops, t: ops.equalize_hist(t), img)
             params = {"method": "Histogram Equalization"}
-            return {"dataURL": codec.to_data_url_png(img_eq), "message": "Histogram Equalized", "params": params}, 200
+            return {"dataURL": data_url(b, img_eq), "message": "Histogram Equalized", "params": params}, 200
 
         if mode == "sharpening":                                    # server.py:250-283
-            img = codec.decode_color(data, "rgb")                     # a per-channel filter: the channel order is immaterial
+            img = codec.decode_color_lazy(data)                       # a per-channel filter: the channel order is immaterial
             if img is None:
                 img = ensure_gray_uint8(b, data)
                 is_color = False
@@ -200,7 +240,7 @@ def create_app(backend=None) -> Flask:
                 img_sharp = img
                 method = "No sharpening"
             params = {"method": method, "color": is_color}
-            return {"dataURL": codec.to_data_url_png(img_sharp, "rgb"), "message": f"Sharpened: {method}", "params": params}, 200
+            return {"dataURL": data_url(b, img_sharp, "rgb"), "message": f"Sharpened: {method}", "params": params}, 200
 
         if mode == "median":                                        # server.py:390-441 (NLM step: out of scope)
             def _int(name, dflt):
@@ -223,7 +263,7 @@ def create_app(backend=None) -> Flask:
             if morph < 1:
                 morph = 0
             passes = max(1, min(4, _int("passes", "1")))
-            decoded = codec.decode_unchanged(data, "rgb")             # the reference decodes first (server.py:360): a bad
+            decoded = codec.decode_lazy(data)             # the reference decodes first (server.py:360): a bad
                                                                      # upload is a 500 whatever the parameters say
             if form.get("nlm", "0") == "1":
                 return {"error": "mode 'median' with nlm=1 (cv2.fastNlMeansDenoising) is outside the GPU hot path of this backend"}, 501
@@ -242,14 +282,14 @@ def create_app(backend=None) -> Flask:
                 return t
             out = b.run(pipeline, img)
             params = {"median_k": int(k), "pre_gauss": int(g), "morph_k": int(morph), "passes": int(passes)}
-            return {"dataURL": codec.to_data_url_png(out), "message": "ok", "params": params}, 200
+            return {"dataURL": data_url(b, out), "message": "ok", "params": params}, 200
 
         if mode == "pca":                                           # server.py:353-356
             return {"error": "mode 'pca' has been removed on server. Use 'pca_nn' for PCA+NN inference "
                                      "or 'detect' for object detection."}, 400
 
         if mode in ("gaussian", "box", "sobel"):                    # extension modes (not in the reference)
-            img = codec.decode_unchanged(data, "rgb")                 # per-channel filters: no channel reversal needed
+            img = codec.decode_lazy(data)                 # per-channel filters: no channel reversal needed
             if img.dtype == np.uint16:
                 img = (img >> 8).astype(np.uint8)
             if img.ndim == 3 and img.shape[2] == 4:
@@ -265,11 +305,11 @@ def create_app(backend=None) -> Flask:
                 out = b.run(lambda ops, t: ops.box3(t), img)
             else:
                 out = b.run(lambda ops, t: ops.sobel(t), img)
-            return {"dataURL": codec.to_data_url_png(out, "rgb"), "message": "ok", "params": params}, 200
+            return {"dataURL": data_url(b, out, "rgb"), "message": "ok", "params": params}, 200
 
         # every other mode works on grayscale (server.py:358-360); unknown modes return plain gray.  The decode comes
         # first, as in the reference: an undecodable upload answers 500 even when a parameter is missing too
-        img = codec.decode_unchanged(data, "rgb")
+        img = codec.decode_lazy(data)
         lut = None
         if mode in ("gamma", "powerlaw", "power-law"):              # server.py:362-373
             gamma_param = form.get("gamma") or form.get("gamma_value") or form.get("g")
@@ -303,7 +343,7 @@ def create_app(backend=None) -> Flask:
         else:
             gray = gray_from_decoded(b, img)
             out = gray if lut is None else b.run(lambda ops, t: ops.apply_lut(t, lut), gray)
-        return {"dataURL": codec.to_data_url_png(out), "message": "ok", "params": params}, 200
+        return {"dataURL": data_url(b, out), "message": "ok", "params": params}, 200
 
     def respond(payload, status):
         """jsonify, except that the data URLs (tens of MB of base64 that needs no escaping) are spliced in instead of

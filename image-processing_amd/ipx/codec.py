@@ -24,6 +24,8 @@ def _open(img_bytes: bytes, exif_orientation: bool = False) -> Image.Image:
         pre = getattr(_TLS, "prefetched", None)
         if pre is not None and pre.blob is img_bytes:
             im = pre.fut.result()                                     # decoded ahead by the pool (raises what it raised)
+            if isinstance(im, LazyPng):                               # (a caller that wants the pixels on the host)
+                im = Image.fromarray(im.array())
         else:
             im = Image.open(io.BytesIO(img_bytes))
             im.load()
@@ -47,6 +49,9 @@ class DecodeAhead:
 
     @staticmethod
     def _decode(b):
+        got = png_scanlines(b)                                        # inflate only; the GPU un-filters (decode_lazy)
+        if got is not None and got[3] == 8 and got[2] in (1, 3, 4):
+            return LazyPng(b, got[0], got[1], got[2], got[4])
         im = Image.open(io.BytesIO(b))
         im.load()
         return im
@@ -69,6 +74,99 @@ class _Prefetched:
 
 
 _TLS = threading.local()
+
+
+# ---- PNG fast path: inflate here, un-filter on the GPU ---------------------------------------------------------------
+_PNG_SIG = b"\x89PNG\r\n\x1a\n"
+_PNG_CHANNELS = {0: 1, 2: 3, 4: 2, 6: 4}                 # colour type -> samples per pixel (palette images: Pillow)
+
+
+def png_scanlines(img_bytes: bytes):
+    """Parses a non-interlaced 8- or 16-bit gray / gray+alpha / RGB / RGBA PNG and inflates its IDAT stream (zlib releases the
+    GIL): returns (w, h, channels, bit depth, filtered scan lines as bytes), or None for anything else -- palette, sub-byte
+    depths, Adam7, colour-key transparency (tRNS), an eXIf orientation chunk, a damaged stream, a filter type byte above 4:
+    the caller then takes Pillow's decoder, which either handles the case or raises what it raises.  Chunk CRCs are not
+    checked here (a stream that inflates to exactly h scan lines with valid filter types is taken as it is)."""
+    b = img_bytes
+    if len(b) < 33 or b[:8] != _PNG_SIG or b[12:16] != b"IHDR":
+        return None
+    w, h, depth, color, comp, filt, lace = struct.unpack(">IIBBBBB", b[16:29])
+    if depth not in (8, 16) or color not in _PNG_CHANNELS or comp or filt or lace or w == 0 or h == 0:
+        return None
+    pos, idat, n = 33, [], len(b)
+    while pos + 8 <= n:
+        ln = int.from_bytes(b[pos:pos + 4], "big")
+        tag = b[pos + 4:pos + 8]
+        if tag == b"IDAT":
+            idat.append(b[pos + 8:pos + 8 + ln])
+        elif tag in (b"tRNS", b"eXIf", b"acTL"):
+            return None
+        elif tag == b"IEND":
+            break
+        pos += 12 + ln
+    else:
+        return None                                                   # no IEND: truncated
+    ch = _PNG_CHANNELS[color]
+    stride = 1 + w * ch * (depth // 8)
+    try:
+        d = zlib.decompressobj()
+        raw = d.decompress(idat[0] if len(idat) == 1 else b"".join(idat), h * stride + 1)
+        if len(raw) != h * stride or not d.eof and d.decompress(d.unconsumed_tail, 1):
+            return None
+    except zlib.error:
+        return None
+    if np.frombuffer(raw, np.uint8)[::stride].max() > 4:
+        return None
+    return w, h, ch, depth, raw
+
+
+class LazyPng:
+    """An 8-bit gray / RGB / RGBA PNG decoded as far as the host goes: inflated, not yet un-filtered.  Looks like the array
+    decode_unchanged(..., "rgb") would return (shape, ndim, dtype); GpuBackend uploads `raw` and reconstructs the pixels
+    on the GPU (ipx_png_unfilter_u8).  Anything that needs the pixels on the host (indexing, numpy functions) gets them from
+    Pillow's decoder, once."""
+
+    dtype = np.dtype(np.uint8)
+
+    def __init__(self, blob: bytes, w: int, h: int, channels: int, raw: bytes):
+        self.blob, self.w, self.h, self.channels, self.raw = blob, w, h, channels, raw
+        self.shape = (h, w) if channels == 1 else (h, w, channels)
+        self.ndim = len(self.shape)
+        self.size = h * w * channels
+        self._array = None
+
+    def array(self) -> np.ndarray:
+        if self._array is None:
+            im = Image.open(io.BytesIO(self.blob))
+            im.load()
+            self._array = np.array(im, dtype=np.uint8)
+            if self._array.shape != self.shape:
+                raise RuntimeError("Cannot decode image to grayscale 8-bit. unknown error")
+        return self._array
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.array()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __getitem__(self, idx):
+        return self.array()[idx]
+
+
+def decode_lazy(img_bytes: bytes, exif_orientation: bool = False):
+    """decode_unchanged(img_bytes, "rgb") for callers that hand the result to GpuBackend.run: an 8-bit gray / RGB / RGBA PNG
+    comes back as a LazyPng (un-filtered on the GPU), everything else as the numpy array Pillow decodes."""
+    pre = getattr(_TLS, "prefetched", None)
+    got = None
+    if pre is not None and pre.blob is img_bytes:
+        res = pre.fut.result() if pre.fut.exception() is None else None    # (an error is re-raised, in the reference's
+        if isinstance(res, LazyPng):                                       # words, by _open below)
+            return res
+    else:
+        got = png_scanlines(img_bytes)
+    if got is not None and got[3] == 8 and got[2] in (1, 3, 4):
+        w, h, ch, _, raw = got
+        return LazyPng(img_bytes, w, h, ch, raw)
+    return decode_unchanged(img_bytes, "rgb", exif_orientation)
 
 
 def decode_unchanged(img_bytes: bytes, order: str = "bgr", exif_orientation: bool = False) -> np.ndarray:
@@ -107,6 +205,21 @@ def decode_color(img_bytes: bytes, order: str = "bgr"):
     return a if a.shape[2] == 3 else np.ascontiguousarray(a[:, :, :3])
 
 
+def decode_color_lazy(img_bytes: bytes):
+    """decode_color(img_bytes, "rgb") for GpuBackend.run: an 8-bit RGB PNG without an orientation chunk comes back as a
+    LazyPng, everything else as decode_color returns it (H x W x 3 uint8, or None)."""
+    pre = getattr(_TLS, "prefetched", None)
+    if pre is not None and pre.blob is img_bytes:
+        res = pre.fut.result() if pre.fut.exception() is None else None
+        if isinstance(res, LazyPng) and res.channels == 3:
+            return res
+    else:
+        got = png_scanlines(img_bytes)
+        if got is not None and got[3] == 8 and got[2] == 3:
+            return LazyPng(img_bytes, got[0], got[1], 3, got[4])
+    return decode_color(img_bytes, "rgb")
+
+
 _POOL = None
 _POOL_LOCK = threading.Lock()
 _BAND_BYTES = 1 << 20            # filtered bytes per independently deflated band
@@ -125,11 +238,34 @@ def _chunk(tag: bytes, data: bytes) -> bytes:
     return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(data, zlib.crc32(tag)) & 0xFFFFFFFF)
 
 
+def adler32_combine(a1: int, a2: int, len2: int) -> int:
+    """Adler-32 of two concatenated blocks from the checksums of each and the length of the second (zlib's
+    adler32_combine, which Python's zlib module does not expose): lets the bands be summed on the pool."""
+    base = 65521
+    rem = len2 % base
+    s1 = a1 & 0xFFFF
+    s2 = (rem * s1) % base
+    s1 += (a2 & 0xFFFF) + base - 1
+    s2 += ((a1 >> 16) & 0xFFFF) + ((a2 >> 16) & 0xFFFF) + base - rem
+    if s1 >= base:
+        s1 -= base
+    if s1 >= base:
+        s1 -= base
+    if s2 >= (base << 1):
+        s2 -= base << 1
+    if s2 >= base:
+        s2 -= base
+    return s1 | (s2 << 16)
+
+
 def encode_png(img: np.ndarray, level: int = 1) -> bytes:
     """PNG writer for H x W (gray) or H x W x 3 (RGB order) uint8 whose deflate work runs on all host cores: the
     'Up'-filtered scan lines are cut into bands, every band is deflated on its own (zlib releases the GIL) and ends on a
-    byte boundary (Z_SYNC_FLUSH), and the bands are concatenated into ONE zlib stream, as pigz does.  PNG encoding is
-    the largest part of a request (scripts/e2ebench.py); the decoded pixels are what the contract fixes, not these bytes."""
+    byte boundary (Z_SYNC_FLUSH), and the bands are concatenated into ONE zlib stream, as pigz does.  Each band becomes an
+    IDAT chunk of its own, so that its CRC-32 and its share of the stream's Adler-32 are computed by the same pool thread
+    (28 ms of serial checksumming per 4K colour frame otherwise); the stream's 2-byte header and 4-byte trailer are two
+    tiny IDAT chunks around them.  PNG encoding is the largest part of a request (scripts/e2ebench.py); the decoded
+    pixels are what the contract fixes, not these bytes."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
     h, w = img.shape[:2]
     rows = img.reshape(h, -1)
@@ -143,16 +279,23 @@ def encode_png(img: np.ndarray, level: int = 1) -> bytes:
 
     def deflate(i):
         co = zlib.compressobj(level, zlib.DEFLATED, -15)
-        return co.compress(bands[i]) + co.flush(zlib.Z_FINISH if i == len(bands) - 1 else zlib.Z_SYNC_FLUSH)
+        data = co.compress(bands[i]) + co.flush(zlib.Z_FINISH if i == len(bands) - 1 else zlib.Z_SYNC_FLUSH)
+        return _chunk(b"IDAT", data), zlib.adler32(bands[i]), bands[i].size
 
     parts = [deflate(0)] if len(bands) == 1 else list(_pool().map(deflate, range(len(bands))))
-    stream = b"\x78\x01" + b"".join(parts) + struct.pack(">I", zlib.adler32(flat) & 0xFFFFFFFF)
+    adler = 1
+    for _, a, n in parts:
+        adler = adler32_combine(adler, a, n)
     ihdr = struct.pack(">IIBBBBB", w, h, 8, 0 if img.ndim == 2 else 2, 0, 0, 0)
-    return b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", stream) + _chunk(b"IEND", b"")
+    return b"".join([_PNG_SIG, _chunk(b"IHDR", ihdr), _chunk(b"IDAT", b"\x78\x01")] + [p[0] for p in parts] +
+                    [_chunk(b"IDAT", struct.pack(">I", adler & 0xFFFFFFFF)), _chunk(b"IEND", b"")])
 
 
-def to_data_url_png(img: np.ndarray, order: str = "bgr") -> str:
-    """server.py:533-538.  `img` is H x W gray or H x W x 3 uint8, BGR unless order="rgb"."""
+def to_data_url_png(img: np.ndarray, order: str = "bgr", b64=None) -> str:
+    """server.py:533-538.  `img` is H x W gray or H x W x 3 uint8, BGR unless order="rgb".  b64: bytes -> ASCII str
+    (GpuBackend.b64encode); default: the host's base64 module."""
+    if b64 is None:
+        b64 = lambda data: base64.b64encode(data).decode("ascii")
     img = np.asarray(img)
     if img.ndim == 3 and img.shape[2] == 1:
         img = img[:, :, 0]
@@ -161,8 +304,8 @@ def to_data_url_png(img: np.ndarray, order: str = "bgr") -> str:
     if img.dtype != np.uint8 or img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] != 3) or img.size == 0:
         buf = io.BytesIO()                                             # anything unusual: Pillow's writer
         Image.fromarray(np.ascontiguousarray(img)).save(buf, format="PNG", compress_level=1)
-        return "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode("ascii")
-    return "data:image/png;base64," + base64.b64encode(encode_png(img)).decode("ascii")
+        return "data:image/png;base64," + b64(buf.getvalue())
+    return "data:image/png;base64," + b64(encode_png(img))
 
 
 def from_data_url_png(url: str) -> np.ndarray:

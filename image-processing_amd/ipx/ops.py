@@ -504,3 +504,36 @@ def erode(src, se): return _morph(src, se, 0)
 def dilate(src, se): return _morph(src, se, 1)
 def morph_open(src, se): return dilate(erode(src, se), se)      # cv2.morphologyEx(MORPH_OPEN), server.py:433
 def morph_close(src, se): return erode(dilate(src, se), se)     # cv2.morphologyEx(MORPH_CLOSE), server.py:434
+
+
+# ---- decode staging ---------------------------------------------------------------------------------
+def png_unfilter(raw: torch.Tensor, h: int, w: int, bytes_per_pixel: int):
+    """PNG reconstruction (un-filtering, PNG specification section 9) of inflated scan lines on the GPU: `raw` is a flat
+    uint8 CUDA tensor holding h rows of [filter type][w * bytes_per_pixel filtered bytes].  Returns (pixels, status):
+    pixels (h, w * bytes_per_pixel) uint8 in file order (16-bit samples big-endian); status a 1-element int32 tensor that is 0
+    when the pixels are valid (read it after the stream is synchronised; see ipx_png_unfilter_u8)."""
+    if not isinstance(raw, torch.Tensor) or raw.dtype != torch.uint8 or not raw.is_cuda or not raw.is_contiguous():
+        raise TypeError("raw: contiguous uint8 CUDA tensor expected (no CPU fallback)")
+    stride = 1 + w * bytes_per_pixel
+    if h <= 0 or w <= 0 or raw.numel() < h * stride:
+        raise ValueError(f"raw holds {raw.numel()} bytes, {h} rows of {stride} expected")
+    with _OnDevice(raw.device):
+        out = torch.empty((h, w * bytes_per_pixel), dtype=torch.uint8, device=raw.device)
+        status = torch.empty((1,), dtype=torch.int32, device=raw.device)
+        nws = _lib.load().ipx_png_unfilter_workspace_bytes(h, w, bytes_per_pixel)
+        ws = torch.empty((nws,), dtype=torch.uint8, device=raw.device)
+        _lib.call("ipx_png_unfilter_u8", _stream(), raw.data_ptr(), stride, out.data_ptr(), w * bytes_per_pixel,
+                  h, w, bytes_per_pixel, ws.data_ptr(), ws.numel(), status.data_ptr())
+    return out, status
+
+
+def base64_encode(data: torch.Tensor) -> torch.Tensor:
+    """base64.b64encode (server.py:536) of a flat uint8 CUDA tensor -> uint8 tensor of 4 * ceil(n / 3) ASCII characters."""
+    if not isinstance(data, torch.Tensor) or data.dtype != torch.uint8 or not data.is_cuda or data.ndim != 1 or not data.is_contiguous():
+        raise TypeError("data: flat contiguous uint8 CUDA tensor expected (no CPU fallback)")
+    n = data.numel()
+    with _OnDevice(data.device):
+        out = torch.empty((4 * ((n + 2) // 3),), dtype=torch.uint8, device=data.device)
+        if n:
+            _lib.call("ipx_base64_encode_u8", _stream(), data.data_ptr(), n, out.data_ptr())
+    return out

@@ -251,6 +251,26 @@ int ipx_morph_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, i
                  int64_t dst_row_stride, int64_t dst_img_stride,
                  int op, const uint8_t* se_host, int se_rows, int se_cols);
 
+/* ---- decode staging ----------------------------------------- */
+
+/* The reconstruction ("un-filtering") stage of PNG decoding, PNG specification section 9 -- inside the reference it is
+ * part of cv2.imdecode (server.py:499 IMREAD_UNCHANGED, :252 IMREAD_COLOR; libpng's row filters).  The host inflates the
+ * IDAT stream (zlib) and hands the filtered scan lines over as they are: `raw` holds h rows of [filter type byte]
+ * [w * bytes_per_pixel filtered bytes], raw_row_stride bytes apart (>= 1 + w * bytes_per_pixel); dst receives the h rows of
+ * reconstructed bytes.  bytes_per_pixel: 1, 2, 3, 4, 6 or 8 (gray, gray + alpha, RGB, RGBA at 8 or 16 bits per sample;
+ * samples stay in file order, 16-bit ones big-endian).  Non-interlaced images only; palette and sub-byte depths are the
+ * host's business.  workspace: ipx_png_unfilter_workspace_bytes(h, w, bytes_per_pixel) bytes of device memory, contents
+ * don't matter (the call clears what it needs).  *status_dev (device uint32) is set to 0, then bit 0 if a row carried a
+ * filter type above 4 (not a PNG: that row is copied unfiltered), bit 1 if a wave gave up waiting for the rows above it
+ * (never seen; the bound exists so that no wave can spin for ever): the pixels are valid only if it reads 0 afterwards. */
+size_t ipx_png_unfilter_workspace_bytes(int h, int w, int bytes_per_pixel);
+int ipx_png_unfilter_u8(void* stream, const uint8_t* raw, int64_t raw_row_stride, uint8_t* dst, int64_t dst_row_stride,
+                        int h, int w, int bytes_per_pixel, void* workspace, size_t workspace_bytes, uint32_t* status_dev);
+
+/* base64.b64encode(buf) of the encoded PNG -- server.py:536 (RFC 4648 standard alphabet, '=' padding).  src: n bytes
+ * (device, 4-byte aligned); dst: 4 * ceil(n / 3) characters (device, 16-byte aligned). */
+int ipx_base64_encode_u8(void* stream, const uint8_t* src, int64_t n, uint8_t* dst);
+
 #ifdef __cplusplus
 }
 #endif

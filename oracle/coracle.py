@@ -109,3 +109,26 @@ def sep_filter_q8_u8(img, kx, ky):
 def gaussian_blur_u8(img, k, sigma=0.0):
     q = gauss_kernel_q8(k, sigma)
     return sep_filter_q8_u8(img, q, q)
+
+
+def png_unfilter(raw, h, w, bpp):
+    """PNG reconstruction of h inflated scan lines ([type][w*bpp bytes] each) -> (h, w*bpp) uint8; raises on a bad type byte."""
+    raw = np.ascontiguousarray(raw, np.uint8).reshape(-1)
+    stride = 1 + w * bpp
+    assert raw.size >= h * stride
+    out = np.empty((h, w * bpp), np.uint8)
+    rc = lib().orc_png_unfilter(_p(raw), C.c_size_t(stride), _p(out), int(h), int(w), int(bpp))
+    if rc:
+        raise ValueError(f"row {rc - 1}: filter type above 4")
+    return out
+
+
+def png_filter(img, bpp, types):
+    """Forward PNG filters: img (h, w*bpp) uint8, types[y] in 0..4 -> the filtered scan lines, flat (h * (1 + w*bpp))."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, L = img.shape
+    types = np.ascontiguousarray(types, np.uint8)
+    assert types.size == h and L % bpp == 0
+    raw = np.empty((h, 1 + L), np.uint8)
+    lib().orc_png_filter(_p(img), _p(raw), C.c_size_t(1 + L), int(h), int(L // bpp), int(bpp), _p(types))
+    return raw.reshape(-1)

@@ -176,3 +176,58 @@ void orc_sep_q8_u8(const uint8_t* src, uint8_t* dst, int h, int w, int cn,
     }
     free(tmp);
 }
+
+/* PNG reconstruction (un-filtering), PNG specification (ISO/IEC 15948) section 9.2-9.4: what libpng does inside
+ * cv2.imdecode (server.py:499, :252) after inflating IDAT.  raw: h rows of [type][w*bpp filtered bytes] `stride` apart;
+ * out: h rows of w*bpp bytes.  Returns 0, or 1 + the first row whose type byte is above 4. */
+int orc_png_unfilter(const uint8_t* raw, size_t stride, uint8_t* out, int h, int w, int bpp)
+{
+    const size_t L = (size_t)w * bpp;
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* f = raw + (size_t)y * stride;
+        const int t = f[0];
+        f += 1;
+        uint8_t* x = out + (size_t)y * L;
+        const uint8_t* up = y ? x - L : NULL;
+        if (t > 4) return 1 + y;
+        for (size_t i = 0; i < L; ++i) {
+            const int a = i >= (size_t)bpp ? x[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
+            int pred = 0;
+            if (t == 1) pred = a;
+            else if (t == 2) pred = b;
+            else if (t == 3) pred = (a + b) >> 1;
+            else if (t == 4) {
+                const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            }
+            x[i] = (uint8_t)(f[i] + pred);
+        }
+    }
+    return 0;
+}
+
+/* the inverse, for building test streams: filter row y with type types[y] (forward filters of section 9.2) */
+void orc_png_filter(const uint8_t* img, uint8_t* raw, size_t stride, int h, int w, int bpp, const uint8_t* types)
+{
+    const size_t L = (size_t)w * bpp;
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* x = img + (size_t)y * L;
+        const uint8_t* up = y ? x - L : NULL;
+        uint8_t* f = raw + (size_t)y * stride;
+        const int t = types[y];
+        f[0] = (uint8_t)t;
+        f += 1;
+        for (size_t i = 0; i < L; ++i) {
+            const int a = i >= (size_t)bpp ? x[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
+            int pred = 0;
+            if (t == 1) pred = a;
+            else if (t == 2) pred = b;
+            else if (t == 3) pred = (a + b) >> 1;
+            else if (t == 4) {
+                const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            }
+            f[i] = (uint8_t)(x[i] - pred);
+        }
+    }
+}
