@@ -36,12 +36,17 @@ if tr:
             f.write(f"\"{k}\",{cnt},{m:.1f},{med:.1f}\n")
 pmc = collections.defaultdict(dict)
 for which, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    # full-batch launches only (largest grid of each kernel), as for the durations above: bench.py's latency section
+    # launches the same kernels on ONE frame, and a mean over every launch mixes the two (round 2's "0.95 x the
+    # algorithmic bytes" for the band kernel and the first r03 table's 0.83 were exactly that mean)
     vals = collections.defaultdict(list)
     for r in csv.DictReader(open(glob.glob(os.path.join(src, which, "*", "*counter_collection.csv"))[0])):
         if r["Counter_Name"] == ctr:
-            vals[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+            vals[short(r["Kernel_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     for k, v in vals.items():
-        pmc[k][ctr] = sum(v) / len(v)
+        gmax = max(g for g, _ in v)
+        full = [x for g, x in v if g == gmax]
+        pmc[k][ctr] = sum(full) / len(full)
 bench = json.load(open(os.path.join(src, "bench.json")))
 B = bench["config"]["batch_per_gpu"]
 px = B * 2160 * 3840
