@@ -305,6 +305,67 @@ int launch_gray(const char* fn, void* stream, const uint8_t* src, uint8_t* dst, 
     return IPX_OK;
 }
 
+// 16-bit sources (server.py:516-523): cv2.cvtColor(img, COLOR_BGR2GRAY) on uint16 -- OpenCV's RGB2Gray<ushort>, the same Q15
+// coefficients as for bytes: gray16 = (3735 B + 19235 G + 9798 R + 16384) >> 15 (at most 65535 * 32768 + 16384 < 2^31) -- then
+// (img >> 8).astype(uint8).  C = samples per pixel: 1 and 2 (gray, gray + alpha) only shift, 3 and 4 convert (alpha dropped).
+// BE: samples big-endian, as a PNG stores them; RGB: R first (file order) instead of OpenCV's B first.  A thread takes 8 pixels:
+// C 16-byte loads, one 8-byte store.
+template <int C, bool BE, bool RGB>
+__device__ __forceinline__ uint32_t gray16_px(const uint32_t (&w)[4 * C], int px)           // static indices after unrolling
+{
+    auto sample = [&](int idx) -> uint32_t {
+        uint32_t v = (w[idx >> 1] >> (16 * (idx & 1))) & 0xffffu;
+        if (BE) v = ((v & 0xffu) << 8) | (v >> 8);
+        return v;
+    };
+    if (C < 3) return sample(px * C) >> 8;
+    const uint32_t c0 = sample(px * C), c1 = sample(px * C + 1), c2 = sample(px * C + 2);
+    return gray_q15(RGB ? c2 : c0, c1, RGB ? c0 : c2) >> 8;
+}
+
+template <int C, bool BE, bool RGB>
+__global__ __launch_bounds__(kThreads) void gray16_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, PwGeom g)
+{
+    const unsigned img = blockIdx.y;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    for (unsigned u = blockIdx.x; u < g.units_per_img; u += gridDim.x) {
+        const unsigned row = u / g.units_per_row;
+        const int64_t x = (int64_t)(u - row * g.units_per_row) * (kThreads * 8) + (int64_t)threadIdx.x * 8;
+        const uint8_t* sp = simg + (int64_t)row * g.s_row;
+        uint8_t* dp = dimg + (int64_t)row * g.d_row;
+        if (x + 8 <= g.len) {
+            uint32_t w[4 * C];
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const u32x4 v = ld16_nt(sp + x * (2 * C) + 16 * i);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[4 * i + q] = v[q];
+            }
+            u32x2 o = {0u, 0u};
+#pragma unroll
+            for (int px = 0; px < 8; ++px) o[px >> 2] |= gray16_px<C, BE, RGB>(w, px) << (8 * (px & 3));
+            __builtin_nontemporal_store(o, (u32x2_u*)(dp + x));
+        } else {
+            for (int64_t q = x; q < g.len; ++q) {
+                const uint8_t* s = sp + q * (2 * C);
+                auto sample = [&](int ch) -> uint32_t {
+                    return BE ? ((uint32_t)s[2 * ch] << 8 | s[2 * ch + 1]) : ((uint32_t)s[2 * ch + 1] << 8 | s[2 * ch]);
+                };
+                dp[q] = (uint8_t)(C < 3 ? sample(0) >> 8 : gray_q15(sample(RGB ? 2 : 0), sample(1), sample(RGB ? 0 : 2)) >> 8);
+            }
+        }
+    }
+}
+
+template <int C>
+void launch_gray16_c(hipStream_t st, dim3 grid, const uint8_t* s, uint8_t* d, const PwGeom& g, bool be, bool rgb)
+{
+    auto k = be ? (rgb ? gray16_kernel<C, true, true> : gray16_kernel<C, true, false>)
+                : (rgb ? gray16_kernel<C, false, true> : gray16_kernel<C, false, false>);
+    hipLaunchKernelGGL(k, grid, dim3(kThreads), 0, st, s, d, g);
+}
+
 }  // namespace
 
 extern "C" {
@@ -381,6 +442,39 @@ int ipx_bgr2gray_lut_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, i
     if (!lut_host) { ipx_clear_error(); return ipx_fail(IPX_ERR_INVALID, "ipx_bgr2gray_lut_u8: null table"); }
     return launch_gray("ipx_bgr2gray_lut_u8", stream, src, dst, n, h, w, src_channels, src_row_stride, src_img_stride,
                        dst_row_stride, dst_img_stride, lut_host);
+}
+
+int ipx_gray_from_u16_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int src_channels, int flags,
+                         int64_t src_row_stride, int64_t src_img_stride, int64_t dst_row_stride, int64_t dst_img_stride)
+{
+    const char* fn = "ipx_gray_from_u16_u8";
+    ipx_clear_error();
+    if (src_channels < 1 || src_channels > 4)
+        return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: src_channels=%d (1..4 16-bit samples per pixel expected)", fn, src_channels);
+    if (flags & ~(IPX_U16_BIG_ENDIAN | IPX_U16_RGB_ORDER)) return ipx_fail(IPX_ERR_INVALID, "%s: unknown flags 0x%x", fn, (unsigned)flags);
+    if (int rc = ipx_check_image_args(fn, src, dst, n, h, w, 1, 1, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride)) return rc;
+    const int64_t row_bytes = (int64_t)w * 2 * src_channels;                     // (the helper above knows 1..4 BYTES per pixel)
+    if (src_row_stride < row_bytes) return ipx_fail(IPX_ERR_INVALID, "%s: src_row_stride %lld < %lld row bytes", fn, (long long)src_row_stride, (long long)row_bytes);
+    if (n > 1 && src_img_stride < src_row_stride * (int64_t)(h - 1) + row_bytes)
+        return ipx_fail(IPX_ERR_INVALID, "%s: src_img_stride %lld smaller than one image", fn, (long long)src_img_stride);
+    constexpr int unit = kThreads * 8;
+    PwGeom g = make_geom(h, (int64_t)w, 2 * src_channels, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride, unit);
+    if (int rc = check_units(fn, g, h, w, unit)) return rc;
+    const bool be = (flags & IPX_U16_BIG_ENDIAN) != 0, rgb = (flags & IPX_U16_RGB_ORDER) != 0;
+    for (int i0 = 0; i0 < n; i0 += 65535) {
+        const int nb = n - i0 < 65535 ? n - i0 : 65535;
+        const uint8_t* s = src + (int64_t)i0 * src_img_stride;
+        uint8_t* d = dst + (int64_t)i0 * dst_img_stride;
+        const dim3 grid = make_grid(g, nb);
+        switch (src_channels) {
+        case 1: launch_gray16_c<1>((hipStream_t)stream, grid, s, d, g, be, rgb); break;
+        case 2: launch_gray16_c<2>((hipStream_t)stream, grid, s, d, g, be, rgb); break;
+        case 3: launch_gray16_c<3>((hipStream_t)stream, grid, s, d, g, be, rgb); break;
+        default: launch_gray16_c<4>((hipStream_t)stream, grid, s, d, g, be, rgb); break;
+        }
+        IPX_LAUNCH_CHECK("gray16_kernel");
+    }
+    return IPX_OK;
 }
 
 }  // extern "C"

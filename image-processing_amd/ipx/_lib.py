@@ -32,6 +32,7 @@ SIGNATURES = {
     "ipx_last_error": (C.c_char_p, []),
     "ipx_check_device": (_i, []),
     "ipx_bgr2gray_u8": (_i, _IMG + [_i] + _STR),
+    "ipx_gray_from_u16_u8": (_i, _IMG + [_i, _i] + _STR),
     "ipx_lut_u8": (_i, _IMG + [_i] + _STR + [_vp]),
     "ipx_lut_dev_u8": (_i, _IMG + [_i] + _STR + [_vp, _i64]),
     "ipx_lut_multi_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i] + _STR + [_vp, _i64]),

@@ -61,7 +61,7 @@ class GpuBackend:
             bad = any(int(st.item()) != 0 for st in self._tls.png_status)   # (the stream is idle by now)
             self._tls.png_status = []
         if bad:                                                        # never seen: the GPU reconstruction gave up; Pillow's pixels
-            return self.run(fn, *[a.array() if isinstance(a, codec.LazyPng) else a for a in arrays])
+            return self.run(fn, *[a.array() if isinstance(a, (codec.LazyPng, codec.LazyPng16)) else a for a in arrays])
         return host if isinstance(out, tuple) else host[0]
 
     def _upload(self, a, slot: int):
@@ -70,7 +70,7 @@ class GpuBackend:
         buffer is a host memcpy; the H2D copy is asynchronous on this thread's stream and ordered before the next use of
         the buffer by the synchronisation every request ends with (`_download`)."""
         torch = self.torch
-        lazy = a if isinstance(a, codec.LazyPng) else None
+        lazy = a if isinstance(a, (codec.LazyPng, codec.LazyPng16)) else None
         if lazy is not None:                                           # inflated PNG scan lines: the GPU un-filters them
             a = np.frombuffer(lazy.raw, np.uint8)
         else:
@@ -88,7 +88,7 @@ class GpuBackend:
         t = view.to(self.device, non_blocking=True)
         self._tls.upload_pending = True
         if lazy is not None:
-            t, status = self.ops.png_unfilter(t, lazy.h, lazy.w, lazy.channels)
+            t, status = self.ops.png_unfilter(t, lazy.h, lazy.w, lazy.bytes_per_pixel)
             self._tls.png_status.append(status)
             t = t.view(lazy.shape)
         return t
@@ -147,12 +147,16 @@ def to_bgr(t):
 
 def ensure_gray_uint8(backend, img_bytes: bytes) -> np.ndarray:
     """server.py:492-531: decode, drop alpha, BGR->gray (GPU), 16-bit >> 8."""
-    return gray_from_decoded(backend, codec.decode_lazy(img_bytes))
+    return gray_from_decoded(backend, codec.decode_lazy(img_bytes, allow16=True))
 
 
 def gray_from_decoded(backend, img):
     """The part of ensure_gray_uint8 after the decode (`img` in RGB(A) order as decode_unchanged(..., "rgb") or
-    decode_lazy returns it; a gray LazyPng passes through and is reconstructed when it is uploaded)."""
+    decode_lazy returns it; a gray LazyPng passes through and is reconstructed when it is uploaded; a 16-bit PNG is
+    gray-converted on its 16-bit samples and shifted afterwards, in the reference's order, server.py:516-523)."""
+    if isinstance(img, codec.LazyPng16):
+        w, ch = img.w, img.channels
+        return backend.run(lambda ops, t: ops.gray_from_u16(t, w, ch, big_endian=True, rgb_order=True), img)
     if img.ndim == 3:
         img = backend.run(lambda ops, t: ops.bgr2gray(to_bgr(t)), img)  # 3 or 4 channels; alpha dropped
     if img.dtype == np.uint16:
@@ -215,8 +219,11 @@ def create_app(backend=None) -> Flask:
                             "params": params}, 200
 
         if mode == "histogram_eq":                                  # server.py:243-248
-            img = codec.decode_lazy(data)
-            if img.ndim == 3:                                        # colour: gray + histogram in one pass
+            img = codec.decode_lazy(data, allow16=True)
+            if isinstance(img, codec.LazyPng16):                     # 16-bit PNG: gray on 16 bits, >> 8, then equalize
+                w16, ch16 = img.w, img.channels
+                img_eq = b.run(lambda ops, t: ops.equalize_hist(ops.gray_from_u16(t, w16, ch16)), img)
+            elif img.ndim == 3:                                      # colour: gray + histogram in one pass
                 img_eq = b.run(lambda ops, t: ops.bgr2gray_equalize(to_bgr(t))[1], img)
             else:
                 if img.dtype == np.uint16:
@@ -263,7 +270,7 @@ def create_app(backend=None) -> Flask:
             if morph < 1:
                 morph = 0
             passes = max(1, min(4, _int("passes", "1")))
-            decoded = codec.decode_lazy(data)             # the reference decodes first (server.py:360): a bad
+            decoded = codec.decode_lazy(data, allow16=True)   # the reference decodes first (server.py:360): a bad
                                                                      # upload is a 500 whatever the parameters say
             if form.get("nlm", "0") == "1":
                 return {"error": "mode 'median' with nlm=1 (cv2.fastNlMeansDenoising) is outside the GPU hot path of this backend"}, 501
@@ -309,7 +316,9 @@ def create_app(backend=None) -> Flask:
 
         # every other mode works on grayscale (server.py:358-360); unknown modes return plain gray.  The decode comes
         # first, as in the reference: an undecodable upload answers 500 even when a parameter is missing too
-        img = codec.decode_lazy(data)
+        img = codec.decode_lazy(data, allow16=True)
+        if isinstance(img, codec.LazyPng16):                        # (no fused gray + table form for 16-bit samples)
+            img = gray_from_decoded(b, img)
         lut = None
         if mode in ("gamma", "powerlaw", "power-law"):              # server.py:362-373
             gamma_param = form.get("gamma") or form.get("gamma_value") or form.get("g")

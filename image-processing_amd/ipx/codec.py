@@ -24,7 +24,10 @@ def _open(img_bytes: bytes, exif_orientation: bool = False) -> Image.Image:
         pre = getattr(_TLS, "prefetched", None)
         if pre is not None and pre.blob is img_bytes:
             im = pre.fut.result()                                     # decoded ahead by the pool (raises what it raised)
-            if isinstance(im, LazyPng):                               # (a caller that wants the pixels on the host)
+            if isinstance(im, LazyPng16):                             # (a caller that wants what Pillow makes of the file)
+                im = Image.open(io.BytesIO(im.blob))
+                im.load()
+            elif isinstance(im, LazyPng):                             # (a caller that wants the pixels on the host)
                 im = Image.fromarray(im.array())
         else:
             im = Image.open(io.BytesIO(img_bytes))
@@ -52,6 +55,8 @@ class DecodeAhead:
         got = png_scanlines(b)                                        # inflate only; the GPU un-filters (decode_lazy)
         if got is not None and got[3] == 8 and got[2] in (1, 3, 4):
             return LazyPng(b, got[0], got[1], got[2], got[4])
+        if got is not None and got[3] == 16:
+            return LazyPng16(b, got[0], got[1], got[2], got[4])
         im = Image.open(io.BytesIO(b))
         im.load()
         return im
@@ -130,6 +135,7 @@ class LazyPng:
 
     def __init__(self, blob: bytes, w: int, h: int, channels: int, raw: bytes):
         self.blob, self.w, self.h, self.channels, self.raw = blob, w, h, channels, raw
+        self.bytes_per_pixel = channels
         self.shape = (h, w) if channels == 1 else (h, w, channels)
         self.ndim = len(self.shape)
         self.size = h * w * channels
@@ -152,21 +158,87 @@ class LazyPng:
         return self.array()[idx]
 
 
-def decode_lazy(img_bytes: bytes, exif_orientation: bool = False):
+def decode_lazy(img_bytes: bytes, exif_orientation: bool = False, allow16: bool = False):
     """decode_unchanged(img_bytes, "rgb") for callers that hand the result to GpuBackend.run: an 8-bit gray / RGB / RGBA PNG
-    comes back as a LazyPng (un-filtered on the GPU), everything else as the numpy array Pillow decodes."""
+    comes back as a LazyPng (un-filtered on the GPU), everything else as the numpy array Pillow decodes.  allow16: a 16-bit
+    PNG comes back as a LazyPng16 (the caller turns it into gray with ops.gray_from_u16: app.gray_from_decoded)."""
     pre = getattr(_TLS, "prefetched", None)
     got = None
     if pre is not None and pre.blob is img_bytes:
         res = pre.fut.result() if pre.fut.exception() is None else None    # (an error is re-raised, in the reference's
-        if isinstance(res, LazyPng):                                       # words, by _open below)
+        if isinstance(res, LazyPng16):                                     # words, by _open below)
+            if allow16:
+                return res
+        elif isinstance(res, LazyPng):
             return res
     else:
         got = png_scanlines(img_bytes)
     if got is not None and got[3] == 8 and got[2] in (1, 3, 4):
         w, h, ch, _, raw = got
         return LazyPng(img_bytes, w, h, ch, raw)
+    if got is not None and got[3] == 16 and allow16:
+        return LazyPng16(img_bytes, got[0], got[1], got[2], got[4])
     return decode_unchanged(img_bytes, "rgb", exif_orientation)
+
+
+def png_unfilter_host(raw: bytes, h: int, w: int, bpp: int) -> np.ndarray:
+    """PNG reconstruction (specification section 9) on the host, numpy: (h, w * bpp) uint8.  Only what LazyPng16.array() needs --
+    the fall-back when the GPU reconstruction reports a problem (never seen) and test backends without a GPU; rows filtered
+    with Average or Paeth cost a Python loop over their pixels."""
+    L = w * bpp
+    a = np.frombuffer(raw, np.uint8, count=h * (L + 1)).reshape(h, L + 1)
+    out = np.zeros((h, L), np.uint8)
+    zero = np.zeros(L, np.uint8)
+    for y in range(h):
+        t, f = int(a[y, 0]), a[y, 1:]
+        up = out[y - 1] if y else zero
+        if t == 0:
+            out[y] = f
+        elif t == 1:                                                   # Sub: a running sum per byte lane, modulo 256
+            out[y] = np.cumsum(f.reshape(w, bpp), axis=0, dtype=np.uint8).reshape(L)
+        elif t == 2:
+            out[y] = f + up
+        elif t in (3, 4):
+            fr, ur, o = f.reshape(w, bpp).astype(np.int32), up.reshape(w, bpp).astype(np.int32), np.zeros((w, bpp), np.int32)
+            left, ul = np.zeros(bpp, np.int32), np.zeros(bpp, np.int32)
+            for x in range(w):
+                if t == 3:
+                    pred = (left + ur[x]) >> 1
+                else:
+                    p = left + ur[x] - ul
+                    pa, pb, pc = np.abs(p - left), np.abs(p - ur[x]), np.abs(p - ul)
+                    pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, ur[x], ul))
+                left = o[x] = (fr[x] + pred) & 255
+                ul = ur[x]
+            out[y] = o.reshape(L).astype(np.uint8)
+        else:
+            raise RuntimeError("Cannot decode image to grayscale 8-bit. unknown error")
+    return out
+
+
+class LazyPng16:
+    """A 16-bit gray / gray+alpha / RGB / RGBA PNG, inflated but not yet un-filtered (decode_lazy(..., allow16=True)).  The
+    reference gray-converts such a file on its 16-bit samples and shifts afterwards (server.py:516-523); Pillow would hand over
+    8-bit RGB.  GpuBackend uploads `raw`, reconstructs the scan lines on the GPU and gives the consumer an (h, 2 * w * channels)
+    uint8 tensor of big-endian samples in file order -- the input of ops.gray_from_u16.  array() is the same matrix made on the
+    host."""
+
+    depth = 16
+
+    def __init__(self, blob: bytes, w: int, h: int, channels: int, raw: bytes):
+        self.blob, self.w, self.h, self.channels, self.raw = blob, w, h, channels, raw
+        self.bytes_per_pixel = 2 * channels
+        self.shape = (h, w * self.bytes_per_pixel)
+        self._array = None
+
+    def array(self) -> np.ndarray:
+        if self._array is None:
+            self._array = png_unfilter_host(self.raw, self.h, self.w, self.bytes_per_pixel)
+        return self._array
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.array()
+        return a if dtype is None else a.astype(dtype, copy=False)
 
 
 def decode_unchanged(img_bytes: bytes, order: str = "bgr", exif_orientation: bool = False) -> np.ndarray:
@@ -174,9 +246,10 @@ def decode_unchanged(img_bytes: bytes, order: str = "bgr", exif_orientation: boo
     H x W x {3,4} BGR(A) uint8.  order="rgb" skips the channel reversal (a 25 MB host copy at 4K): the caller then
     reverses on the GPU, or not at all for per-channel filters.  IMREAD_UNCHANGED ignores the EXIF orientation tag
     (exif_orientation=False); IMREAD_COLOR applies it (decode_color).
-    Known divergence: a 16-bit COLOUR file reaches the reference as uint16 BGR (gray conversion on 16 bits, then
-    >> 8, server.py:517-523); Pillow hands over 8-bit RGB, so the 8-bit gray formula runs on truncated samples and a
-    pixel can differ by one."""
+    A 16-bit COLOUR file reaches the reference as uint16 BGR (gray conversion on 16 bits, then >> 8, server.py:517-523);
+    Pillow hands over 8-bit RGB.  For PNG files the gray paths therefore go through decode_lazy(..., allow16=True) and
+    ops.gray_from_u16 instead of this function; what remains here is a 16-bit colour file in another container (TIFF),
+    where the 8-bit formula runs on truncated samples and a pixel can differ by one."""
     im = _open(img_bytes, exif_orientation)
     if im.mode in ("L",):
         return np.array(im, dtype=np.uint8)

@@ -130,6 +130,35 @@ def bgr2gray(src: torch.Tensor) -> torch.Tensor:
     return out[0, :, :, 0] if src.ndim == 3 else out
 
 
+def gray_from_u16(src: torch.Tensor, w: int, channels: int, big_endian: bool = True, rgb_order: bool = True) -> torch.Tensor:
+    """The 16-bit branch of ensure_gray_uint8_from_bytes (server.py:516-523): cvtColor(BGR2GRAY) on uint16 samples, then >> 8.
+    `src` holds the samples as BYTES: (h, 2 * w * channels) or (n, h, 2 * w * channels) uint8 -- the scan lines png_unfilter
+    reconstructs (big-endian, R first: the defaults) or a numpy uint16 array viewed as bytes (big_endian=False).  channels 1..4
+    (1, 2: only the shift; 4: alpha dropped).  Returns (h, w) or (n, h, w) uint8."""
+    if not isinstance(src, torch.Tensor) or src.dtype != torch.uint8 or src.ndim not in (2, 3):
+        raise TypeError("src: 2-D or 3-D uint8 tensor of sample bytes expected")
+    if not src.is_cuda:
+        raise RuntimeError(f"src: tensor is on {src.device}; libipx runs on the GPU only (no CPU fallback)")
+    if channels not in (1, 2, 3, 4) or w <= 0 or src.shape[-1] != 2 * w * channels:
+        raise ValueError(f"src rows hold {src.shape[-1]} bytes, 2 x {w} x {channels} expected")
+    v = src if src.ndim == 3 else src[None]
+    if v.stride(2) != 1:
+        v = v.contiguous()
+    n, h = v.shape[0], v.shape[1]
+    if n == 0 or h == 0:
+        raise ValueError(f"src: empty image {tuple(src.shape)}")
+    row = v.stride(1) if h > 1 else v.shape[2]
+    img = v.stride(0) if n > 1 else max(row * h, 1)
+    if row < v.shape[2] or (n > 1 and img < row * (h - 1) + v.shape[2]):
+        v = v.contiguous()
+        row, img = v.shape[2], v.shape[2] * h
+    with _OnDevice(v.device):
+        out = torch.empty((n, h, w), dtype=torch.uint8, device=v.device)
+        _lib.call("ipx_gray_from_u16_u8", _stream(), v.data_ptr(), out.data_ptr(), n, h, w, channels,
+                  (1 if big_endian else 0) | (2 if rgb_order else 0), row, img, w, w * h)
+    return out[0] if src.ndim == 2 else out
+
+
 def apply_lut(src: torch.Tensor, lut) -> torch.Tensor:
     """dst = lut[src] with one 256-entry host table (negative/threshold/gamma/log/piecewise, server.py:362-388,443-467)."""
     s = _Img(src)

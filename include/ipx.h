@@ -60,6 +60,21 @@ int ipx_bgr2gray_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h
                     int64_t src_row_stride, int64_t src_img_stride,
                     int64_t dst_row_stride, int64_t dst_img_stride);
 
+/* The 16-bit branch of ensure_gray_uint8_from_bytes -- server.py:516-523: cv2.cvtColor(img, COLOR_BGR2GRAY) on uint16 (a
+ * 4th sample, alpha, is dropped first, :509-513), then (img >> 8).astype(np.uint8).  OpenCV converts 16-bit samples with the
+ * same Q15 coefficients as bytes: gray16 = (3735*B + 19235*G + 9798*R + 16384) >> 15, dst = gray16 >> 8 -- NOT the 8-bit
+ * formula on the samples' high bytes (the two can differ by one level).  src: n x h x w x src_channels 16-bit samples (given as
+ * bytes: 2 * src_channels per pixel, row_stride >= 2*w*src_channels); src_channels 1 (gray: dst = sample >> 8), 2 (gray + alpha:
+ * the same on the first sample -- OpenCV decodes such a file to B = G = R = gray, whose gray value is gray), 3 or 4.
+ * flags: IPX_U16_BIG_ENDIAN = samples as a PNG file stores them (most significant byte first; the scan lines
+ * ipx_png_unfilter_u8 reconstructs go straight in), else little-endian (a numpy uint16 array); IPX_U16_RGB_ORDER = R first
+ * (file order), else B first (OpenCV's memory order).  dst: n x h x w uint8. */
+#define IPX_U16_BIG_ENDIAN 1
+#define IPX_U16_RGB_ORDER 2
+int ipx_gray_from_u16_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int src_channels, int flags,
+                         int64_t src_row_stride, int64_t src_img_stride,
+                         int64_t dst_row_stride, int64_t dst_img_stride);
+
 /* dst = lut[src] with one 256-entry table given in HOST memory (copied into the launch, the pointer
  * may be reused as soon as the call returns).  Replaces the numpy pixel-wise expressions, each of
  * which is a function of the pixel value alone: negative server.py:376, gamma :370-372, log :385-388

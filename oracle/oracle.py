@@ -46,6 +46,44 @@ def bgr2gray_u8(bgr: np.ndarray) -> np.ndarray:
     return y.astype(np.uint8)
 
 
+def bgr2gray_u16(bgr16: np.ndarray) -> np.ndarray:
+    """`cv2.cvtColor(img, COLOR_BGR2GRAY)` on a uint16 image, server.py:516-517 when the file is a 16-bit colour PNG:
+    OpenCV 4.x RGB2Gray<ushort> uses the same Q15 coefficients as the byte version (gray_shift = 15),
+    `(ushort)CV_DESCALE((unsigned)(b*cb + g*cg + r*cr), 15)`.  A 4th channel is dropped first (server.py:509-513).
+    Parity unpinned, as for every cv2 call (module docstring)."""
+    assert bgr16.dtype == np.uint16 and bgr16.ndim == 3 and bgr16.shape[2] in (3, 4)
+    b = bgr16[..., 0].astype(np.uint64)
+    g = bgr16[..., 1].astype(np.uint64)
+    r = bgr16[..., 2].astype(np.uint64)
+    y = (GRAY_B * b + GRAY_G * g + GRAY_R * r + (1 << (GRAY_SHIFT - 1))) >> GRAY_SHIFT
+    assert int(y.max(initial=0)) <= 65535
+    return y.astype(np.uint16)
+
+
+def gray_u8_from_u16(img16: np.ndarray) -> np.ndarray:
+    """ensure_gray_uint8_from_bytes for a decoded uint16 image, server.py:509-523: H x W stays, H x W x {3,4} BGR(A) is
+    gray-converted on 16 bits; then `>> 8`."""
+    assert img16.dtype == np.uint16
+    if img16.ndim == 3:
+        img16 = bgr2gray_u16(img16)
+    return u16_to_u8_shr8(img16)
+
+
+def gray_u8_from_u16_bytes(raw: np.ndarray, w: int, channels: int, big_endian: bool = True, rgb_order: bool = True) -> np.ndarray:
+    """The same for samples given as bytes (rows of 2 * w * channels bytes, e.g. reconstructed PNG scan lines: big-endian,
+    R first): what ipx_gray_from_u16_u8 computes.  channels 2 = gray + alpha (cv2 decodes it to B = G = R = gray, A)."""
+    raw = np.ascontiguousarray(raw, dtype=np.uint8)
+    h = raw.shape[-2]
+    a = raw.reshape(raw.shape[:-1] + (w, channels, 2)).astype(np.uint16)
+    s = (a[..., 0] << 8 | a[..., 1]) if big_endian else (a[..., 1] << 8 | a[..., 0])
+    if channels < 3:
+        return u16_to_u8_shr8(np.ascontiguousarray(s[..., 0]))
+    bgr = s[..., [2, 1, 0]] if rgb_order else s[..., :3]
+    lead = bgr.shape[:-3]
+    out = u16_to_u8_shr8(bgr2gray_u16(np.ascontiguousarray(bgr.reshape((-1, w, 3)))))
+    return out.reshape(lead + (h, w))
+
+
 def u16_to_u8_shr8(img16: np.ndarray) -> np.ndarray:
     """16-bit -> 8-bit scaling `(img >> 8).astype(uint8)`, server.py:521-523."""
     assert img16.dtype == np.uint16

@@ -35,6 +35,8 @@ class OracleOps:
     @staticmethod
     def bgr2gray(t): return _t(O.bgr2gray_u8(_np(t)))
     @staticmethod
+    def gray_from_u16(t, w, channels, big_endian=True, rgb_order=True): return _t(O.gray_u8_from_u16_bytes(_np(t), w, channels, big_endian, rgb_order))
+    @staticmethod
     def apply_lut(t, lut): return _t(np.asarray(lut, np.uint8)[_np(t)])
     @staticmethod
     def apply_lut_dev(t, luts): return _t(_np(luts).reshape(-1, 256)[0][_np(t)])

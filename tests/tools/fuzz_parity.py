@@ -15,13 +15,14 @@ for p in ("image-processing_amd", "oracle", "tests"):
 import numpy as np
 import torch
 
+import coracle as CO
 import oracle as O
 from ipx import ops
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=90)
 ap.add_argument("--seed", type=int, default=0)
-ap.add_argument("--ops", default="gray,lut,eq,grayeq,sharpen,box3,sobel,gauss,gauss,lee,median,morph,halo,stats")
+ap.add_argument("--ops", default="gray,lut,eq,grayeq,sharpen,box3,sobel,gauss,gauss,lee,median,morph,halo,stats,png,gray16")
 ap.add_argument("--big", action="store_true", help="images of up to ~3 MP and 3000 rows (slower oracle, fewer cases)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
@@ -113,6 +114,50 @@ while time.time() < t_end:
         k = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 15, 17, 21, 25, 31]))
         t, img = make(n, h, w, c, strided)
         fails += check(f"gauss{k}", ops.gaussian_blur(t, k), per_image(lambda x: O.gaussian_blur_u8(x, k), img), (n, h, w, c, strided))
+    elif op == "gaussw":                                     # 9..31 taps on inputs of 2 MB and more: the wave-per-strip kernel
+        c = int(rng.choice([1, 3, 4]))                       # (interior segments + frame pieces; C oracle: the sizes are large)
+        k = int(rng.choice([9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31]))
+        w = int(rng.choice([683, 700, 1024, 1365, 1366, 2048, 2731, 3000])) if rng.random() < 0.5 else int(rng.integers(300, 3200))
+        h = int(rng.integers(max(40, (2 << 20) // (n * w * c) + 1), max(41, (9 << 20) // (n * w * c))))
+        t, img = make(n, h, w, c, strided)
+        fails += check(f"gaussw{k}", ops.gaussian_blur(t, k), per_image(lambda x: CO.gaussian_blur_u8(x, k), img), (n, h, w, c, strided))
+    elif op == "eqbig":                                      # images cut into 65+ histogram blocks: the in-launch finish (tickets)
+        w = int(rng.integers(900, 4200))
+        h = int(rng.integers((1 << 21) // w + 1, (6 << 20) // w))
+        n = int(rng.integers(1, 3))
+        t, img = make(n, h, w, 1, strided)
+        fails += check(op, ops.equalize_hist(t), per_image(CO.equalize_hist_u8, img), (n, h, w, strided))
+        c = int(rng.choice([3, 4]))
+        t, img = make(1, h // 2 + 1, w, c, strided)
+        gray, eq = ops.bgr2gray_equalize(t)
+        g = per_image(CO.bgr2gray_u8, img)
+        fails += check(op + ".gray", gray, g, (1, h // 2 + 1, w, c, strided))
+        fails += check(op + ".grayeq", eq, per_image(CO.equalize_hist_u8, g), (1, h // 2 + 1, w, c, strided))
+    elif op == "png":                                        # PNG reconstruction: random filter types per row
+        bpp = int(rng.choice([1, 2, 3, 4, 6, 8]))
+        w = max(1, min(w, 3000) // bpp)
+        _, img = make(1, h, w * bpp, 1, False)
+        img = img.reshape(h, w * bpp)
+        plan = rng.integers(0, 5, h) if rng.random() < 0.6 else np.full(h, int(rng.integers(0, 5)))
+        raw = CO.png_filter(img, bpp, plan.astype(np.uint8))
+        got, status = ops.png_unfilter(torch.from_numpy(np.ascontiguousarray(raw).reshape(-1)).to(dev), h, w, bpp)
+        fails += check(f"png{bpp}", got, img, (h, w, bpp))
+        if int(status.item()) != 0:
+            print(f"MISMATCH png status {int(status.item())} {(h, w, bpp)}", flush=True)
+            fails += 1
+    elif op == "gray16":                                     # 16-bit samples -> gray -> >> 8
+        c = int(rng.choice([1, 2, 3, 4]))
+        be, rgb = bool(rng.random() < 0.5), bool(rng.random() < 0.5)
+        w = max(1, min(w, 2100))
+        raw = rng.integers(0, 256, (n, h, w * c * 2), dtype=np.uint8)
+        if rng.random() < 0.2:
+            raw[:] = 255
+        t = torch.from_numpy(raw).to(dev)
+        if strided:
+            buf = torch.zeros((n, h, w * c * 2 + 21), dtype=torch.uint8, device=dev)
+            buf[:, :, :w * c * 2] = t
+            t = buf[:, :, :w * c * 2]
+        fails += check(f"gray16.{c}", ops.gray_from_u16(t, w, c, big_endian=be, rgb_order=rgb), O.gray_u8_from_u16_bytes(raw, w, c, be, rgb), (n, h, w, c, be, rgb, strided))
     elif op == "gaussbig":                                   # the generic two-pass path (k > 31)
         c = int(rng.choice([1, 3]))
         k = int(rng.choice([33, 45, 63, 101, 255]))
@@ -126,7 +171,7 @@ while time.time() < t_end:
         fails += check(f"lee{win}", ops.lee_filter(t, win), per_image(lambda x: O.lee_filter_u8(x, win), img), (n, h, w, strided))
     elif op == "median":
         h, w = min(h, 150), min(w, 700)
-        k = int(rng.choice([1, 3, 3, 5, 5, 5, 7, 7, 7, 9, 9, 9, 11, 11, 11, 13, 15, 21, 31]))
+        k = int(rng.choice([1, 3, 3, 5, 5, 5, 7, 7, 7, 9, 9, 9, 11, 11, 11, 13, 13, 15, 15, 17, 19, 21, 23, 25, 27, 29, 31]))
         t, img = make(n, h, w, 1, strided)
         fails += check(f"median{k}", ops.median_blur(t, k), per_image(lambda x: O.median_blur_u8(x, k), img), (n, h, w, strided))
     elif op == "halo":
