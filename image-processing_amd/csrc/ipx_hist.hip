@@ -564,6 +564,28 @@ int scratch_for_stream(const char* fn, hipStream_t st, uint8_t** out)
     return IPX_OK;
 }
 
+// mode=log's table from an image's histogram -- server.py:385-388: s = log1p(c r) (float32, the 256 values come from the
+// host, numpy's own log1p), s /= (s.max() + 1e-12), out = (s * 255.0).astype(uint8).  s increases with the level, so s.max()
+// over the image is s at the highest level present; the 1e-12 is added in float32 (it only survives when that maximum is 0).
+// One block of 256 threads per image; two separately rounded float32 operations per level, then truncation.  Levels above the
+// highest one present are never looked up (numpy's cast of their out-of-range values is unspecified): they read 255.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void log_lut_kernel(const uint32_t* __restrict__ hist, const float* __restrict__ curve,
+                                                      uint8_t* __restrict__ lut, int64_t lut_stride)
+{
+    __shared__ int s_top[4];
+    const int t = (int)threadIdx.x;
+    const uint32_t* h = hist + (size_t)blockIdx.x * 256;
+    const unsigned long long present = __ballot(h[t] != 0u);           // levels 64 w .. 64 w + 63 of wave w
+    if ((t & 63) == 0) s_top[t >> 6] = present ? 64 * (t >> 6) + 63 - __builtin_clzll(present) : -1;
+    __syncthreads();
+    int top = s_top[3] >= 0 ? s_top[3] : s_top[2] >= 0 ? s_top[2] : s_top[1] >= 0 ? s_top[1] : s_top[0];
+    if (top < 0) top = 0;                                              // an all-zero histogram (no pixels): treat as level 0
+    const float d = curve[top] + 1e-12f;
+    const float v = __fdiv_rn(curve[t], d) * 255.0f;
+    lut[(int64_t)blockIdx.x * lut_stride + t] = t > top || !(v < 256.0f) ? (uint8_t)255 : (uint8_t)(int)v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -608,6 +630,17 @@ int ipx_equalize_lut_u8(void* stream, const uint32_t* hist_dev, int n, uint8_t* 
     hipLaunchKernelGGL(hist_finish_kernel, dim3((unsigned)n), dim3(256 * kFinishGroups), 0, (hipStream_t)stream,
                        (const uint32_t*)nullptr, 0u, hist_dev, (uint32_t*)nullptr, lut_dev);
     IPX_LAUNCH_CHECK("hist_finish_kernel");
+    return IPX_OK;
+}
+
+int ipx_log_lut_u8(void* stream, const uint32_t* hist_dev, int n, const float* curve_dev, uint8_t* lut_dev, int64_t lut_stride)
+{
+    ipx_clear_error();
+    if (!hist_dev || !curve_dev || !lut_dev) return ipx_fail(IPX_ERR_INVALID, "ipx_log_lut_u8: null pointer");
+    if (n <= 0) return ipx_fail(IPX_ERR_INVALID, "ipx_log_lut_u8: n=%d must be positive", n);
+    if (lut_stride < 256) return ipx_fail(IPX_ERR_INVALID, "ipx_log_lut_u8: lut_stride %lld must be >= 256", (long long)lut_stride);
+    hipLaunchKernelGGL(log_lut_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, hist_dev, curve_dev, lut_dev, lut_stride);
+    IPX_LAUNCH_CHECK("log_lut_kernel");
     return IPX_OK;
 }
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ipx_hist_workspace_init": (_i, [_vp, _vp, _sz]),
     "ipx_hist_u8": (_i, [_vp, _vp, _i, _i, _i, _i64, _i64, _vp, _vp, _sz]),
     "ipx_equalize_lut_u8": (_i, [_vp, _vp, _i, _vp]),
+    "ipx_log_lut_u8": (_i, [_vp, _vp, _i, _vp, _vp, _i64]),
     "ipx_equalize_hist_u8": (_i, _IMG + _STR + [_vp, _vp, _vp, _sz]),
     "ipx_equalize_hist_noalloc_u8": (_i, _IMG + _STR + [_vp, _vp]),
     "ipx_bgr2gray_equalize_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _sz]),

@@ -279,6 +279,25 @@ def equalize_lut(hists: torch.Tensor) -> torch.Tensor:
     return out.reshape(hists.shape)
 
 
+def log_lut(hists: torch.Tensor, curve: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mode=log's tables (server.py:385-388) from histograms (N,256) int32 and the float32 curve log1p(c * level/255)
+    (256 values on the device, luts.log_curve) -> (N,256) uint8.  `out` may be a row-strided (N,256) view, e.g. one table
+    slot of the N x k x 256 table sets apply_luts_dev takes."""
+    if hists.dtype != torch.int32 or not hists.is_cuda or hists.shape[-1] != 256:
+        raise ValueError("hists: int32 CUDA tensor (..., 256) expected")
+    if curve.dtype != torch.float32 or curve.device != hists.device or curve.numel() != 256 or not curve.is_contiguous():
+        raise ValueError("curve: 256 contiguous float32 values on the histograms' device expected")
+    h2 = hists.reshape(-1, 256).contiguous()
+    n = h2.shape[0]
+    with _OnDevice(h2.device):
+        if out is None:
+            out = torch.empty((n, 256), dtype=torch.uint8, device=h2.device)
+        if out.dtype != torch.uint8 or out.device != h2.device or tuple(out.shape) != (n, 256) or out.stride(1) != 1 or (n > 1 and out.stride(0) < 256):
+            raise ValueError("out: (N,256) uint8 view with unit column stride and row stride >= 256 expected")
+        _lib.call("ipx_log_lut_u8", _stream(), h2.data_ptr(), n, curve.data_ptr(), out.data_ptr(), out.stride(0) if n > 1 else 256)
+    return out
+
+
 def equalize_hist(src: torch.Tensor, return_aux: bool = False):
     """cv2.equalizeHist(img) (server.py:246)."""
     s = _gray(src)

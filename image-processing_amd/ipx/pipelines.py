@@ -25,25 +25,22 @@ def _dev_const(key, device, make):
     return _DEV_CONST[k]
 
 
-def log_tables_dev(hists, c: float = 2.0):
-    """mode=log tables (server.py:385-388) for a batch, built ON THE DEVICE from the images' histograms (N x 256 counts):
-    `s.max()` is per image and `s` increases with the level, so the maximum is `s` at the highest level present; then the
-    reference's two float32 operations per level, `s / (max + 1e-12)` and `* 255`, and the uint8 truncation -- the same
-    IEEE operations torch performs elementwise (checked against luts.log for every possible highest level in
-    tests/test_gpu_parity.py).  No host round trip: the pipeline stays asynchronous."""
+def log_tables_dev(hists, c: float = 2.0, out=None, ops=None):
+    """mode=log tables (server.py:385-388) for a batch, built ON THE DEVICE from the images' histograms (N x 256 counts) by
+    ipx_log_lut_u8: `s.max()` is per image and `s` increases with the level, so the maximum is `s` at the highest level
+    present; then the reference's two float32 operations per level, `s / (max + 1e-12)` and `* 255`, and the uint8
+    truncation (checked against luts.log for every possible highest level in tests/test_gpu_parity.py).  No host round trip:
+    the pipeline stays asynchronous; one launch (round 2 spelled it with nine torch kernels)."""
     import torch
-    dev = hists.device
-    s = _dev_const(("log_curve", float(c)), dev, lambda: torch.from_numpy(luts.log_curve(c)))   # float32 (256,), numpy's log1p
-    levels = _dev_const("levels", dev, lambda: torch.arange(256))
-    eps = _dev_const("eps", dev, lambda: torch.tensor(1e-12, dtype=torch.float32))
-    top = ((hists.reshape(-1, 256) > 0) * levels).amax(dim=1)                         # highest level present, per image
-    d = s[top] + eps
-    return ((s[None, :] / d[:, None]) * 255.0).to(torch.uint8)                        # N x 256
+    if ops is None:
+        from . import ops
+    s = _dev_const(("log_curve", float(c)), hists.device, lambda: torch.from_numpy(luts.log_curve(c)))   # float32 (256,), numpy's log1p
+    return ops.log_lut(hists, s, out)
 
 
 def log_transform(ops, gray, c: float = 2.0):
     """mode=log (server.py:383-388) on a batch: each image gets its OWN table (log_tables_dev), applied in one launch."""
-    return ops.apply_lut_dev(gray, log_tables_dev(ops.hist(gray), c))
+    return ops.apply_lut_dev(gray, log_tables_dev(ops.hist(gray), c, ops=ops))
 
 
 def full_pipeline(ops, bgr) -> dict:
@@ -60,8 +57,11 @@ def full_pipeline(ops, bgr) -> dict:
     n = hists.reshape(-1, 256).shape[0]
     shared = _dev_const("full_pipeline_tables", gray.device,
                         lambda: torch.from_numpy(np.stack([make() for _, make in FULL_PIPELINE_TABLES]).astype(np.uint8)))
-    tabs = torch.cat([shared[None].expand(n, -1, -1), log_tables_dev(hists, 2.0)[:, None, :], eq_lut.reshape(n, 1, 256)],
-                     dim=1).contiguous()                            # N x 6 x 256
+    k = len(FULL_PIPELINE_TABLES)
+    tabs = torch.empty((n, k + 2, 256), dtype=torch.uint8, device=gray.device)      # N x 6 x 256
+    tabs[:, :k] = shared
+    log_tables_dev(hists, 2.0, out=tabs[:, k], ops=ops)
+    tabs[:, k + 1] = eq_lut.reshape(n, 256)
     res = ops.apply_luts_dev(gray if gray.ndim == 4 else gray[None, :, :, None], tabs)
     if gray.ndim != 4:
         res = [r[0, :, :, 0] for r in res]

@@ -142,6 +142,16 @@ int ipx_hist_u8(void* stream, const uint8_t* src, int n, int h, int w,
  * its histogram between ipx_hist_u8 and this call. */
 int ipx_equalize_lut_u8(void* stream, const uint32_t* hist_dev, int n, uint8_t* lut_dev);
 
+/* The table of mode=log from n histograms (device -> device) -- server.py:385-388: r = img/255 (float32), s = np.log1p(c*r),
+ * s /= (s.max() + 1e-12), out = (s*255.0).astype(np.uint8), a function of the pixel value given the image's maximum.
+ * curve_dev: the 256 float32 values log1p(c * level/255) (DEVICE memory; the host evaluates them with numpy so that they are
+ * numpy's bits); s.max() is the curve at the highest level whose histogram count is non-zero.  Image i's table goes to
+ * lut_dev + i*lut_stride (lut_stride >= 256; tables of a batch can be written straight into the per-image table sets of
+ * ipx_lut_multi_u8).  Entries above the highest level present are never looked up and read 255.  For batch pipelines
+ * (BASELINE.json configs[2]) that must not leave the stream for a host round trip; a single request builds the table on the
+ * host (ipx/luts.py) from ipx_hist_u8's counts. */
+int ipx_log_lut_u8(void* stream, const uint32_t* hist_dev, int n, const float* curve_dev, uint8_t* lut_dev, int64_t lut_stride);
+
 /* cv2.equalizeHist(img) -- server.py:246.  hist_out_dev (n*256 uint32) and lut_out_dev (n*256 uint8)
  * may be NULL; when given they receive the histogram and table that were used. */
 int ipx_equalize_hist_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
