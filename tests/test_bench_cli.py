@@ -81,3 +81,26 @@ def test_rowpart_workload_two_ranks_on_one_gpu(dev):
     assert r.returncode == 0, r.stdout + r.stderr
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["config"]["rows_per_rank"] == 2048 and j["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_the_drivers_launch_form_torch_distributed_run(dev):
+    """N > 1 as the driver starts it: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` (one rank per GPU; here both ranks on cuda:0 with gloo in place of
+    RCCL): rank 0 prints the one JSON line, every rank's step time is in it."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(IPX_BENCH_DEVICE="0", IPX_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--cpu-sample", "0"],
+                       env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and len(j["ms_per_step_per_rank"]) == 2 and j["steps"] == 3 and j["warmup"] == 1
+    assert j["value"] > 0 and j["scaling"] == "weak" and j["roofline"]["frac"] > 0
