@@ -512,7 +512,9 @@ def main():
                 ("lee_w5", "lee_small_kernel<5>", 2, lambda: ops.lee_filter(gray, 5)),
                 ("lee_w7", "lee_small_kernel<7>", 2, lambda: ops.lee_filter(gray, 7)),
                 ("lee_w9", "lee_small_kernel<9>", 2, lambda: ops.lee_filter(gray, 9)),
-                ("lee_w31", "lee_kernel", 2, lambda: ops.lee_filter(gray, 31)),
+                ("lee_w11", "lee_wide_kernel<11>", 2, lambda: ops.lee_filter(gray, 11)),
+                ("lee_w15", "lee_wide_kernel<15>", 2, lambda: ops.lee_filter(gray, 15)),
+                ("lee_w31", "lee_wide_kernel<31>", 2, lambda: ops.lee_filter(gray, 31)),
                 ("erode_3", "morph_small_kernel<false,1>", 2, lambda: ops.erode(gray, ops.ellipse_se(3))),
                 ("dilate_5", "morph_small_kernel<true,2>", 2, lambda: ops.dilate(gray, ops.ellipse_se(5))),
                 ("median_3", "median3_kernel", 2, lambda: ops.median_blur(gray, 3)),

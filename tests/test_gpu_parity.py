@@ -587,8 +587,32 @@ def test_lee_filter_golden_and_batch(dev, golden):
     np.testing.assert_array_equal(host(ops.lee_filter(dev_t(extremes, dev), 7)), O.lee_filter_u8(extremes, 7))
 
 
+def test_lee_wide_windows_two_pixels_per_thread(dev):
+    """windows 11 ... 31 run on lee_wide_kernel (a thread owns two adjacent pixels, packed float32, numpy's pairwise order):
+    every window size, widths around the 64-pixel tiles and odd widths (the last pair's right pixel is outside the image),
+    heights around the 8-row tiles, a batch, a row-strided view, flat patches (var == 0) and extremes; golden fixtures
+    of the real lee_filter for 13 ... 31 are in test_lee_filter_golden_and_batch."""
+    rng = np.random.default_rng(77)
+    for wnd in (10, 11, 12, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31):
+        k = wnd // 2
+        for h, w in ((2 * k + 1, 2 * k + 1), (2 * k + 2, 2 * k + 3), (40, 63), (41, 64), (39, 65), (33, 129), (48, 200)):
+            img = np.clip(rng.normal(120, 45, (h, w)), 0, 255).astype(np.uint8)
+            if h > 36 and w > 60:
+                img[2:36, 10:60] = 200                                   # flat: var == 0 inside for the smaller windows
+            np.testing.assert_array_equal(host(ops.lee_filter(dev_t(img, dev), wnd)), O.lee_filter_u8(img, wnd), err_msg=f"{h}x{w} w={wnd}")
+    ext = (rng.integers(0, 2, (45, 90)) * 255).astype(np.uint8)
+    for wnd in (13, 31):
+        np.testing.assert_array_equal(host(ops.lee_filter(dev_t(ext, dev), wnd)), O.lee_filter_u8(ext, wnd))
+    big = rng.integers(0, 256, (3, 50, 150), dtype=np.uint8)
+    view = dev_t(big, dev)[:, 3:47, 5:136].unsqueeze(-1)
+    got = host(ops.lee_filter(view, 15))
+    for i in range(3):
+        np.testing.assert_array_equal(got[i, :, :, 0], O.lee_filter_u8(np.ascontiguousarray(big[i, 3:47, 5:136]), 15))
+
+
 def test_lee_column_walker(dev):
-    """windows 3, 4 (= 5), 5, ... 10 (= 11) and 11 on images at least 64 columns wide run on the column walker (lee_small_kernel): widths around
+    """windows 3, 4 (= 5), 5, ... 9 on images at least 64 columns wide run on the column walker (lee_small_kernel; 10 and 11 take
+    lee_wide_kernel since round 3 and are checked here on the same shapes): widths around
     the 64-column strips and 256-column blocks, heights around the row segments, flat patches (var == 0), two-level and
     near-constant images (tiny variances), a strided batch with an unaligned base; every pixel equal to numpy's result."""
     rng = np.random.default_rng(91)
