@@ -517,6 +517,8 @@ def main():
                 ("lee_w31", "lee_wide_kernel<31>", 2, lambda: ops.lee_filter(gray, 31)),
                 ("erode_3", "morph_small_kernel<false,1>", 2, lambda: ops.erode(gray, ops.ellipse_se(3))),
                 ("dilate_5", "morph_small_kernel<true,2>", 2, lambda: ops.dilate(gray, ops.ellipse_se(5))),
+                ("erode_7", "morph_runs_kernel<false>", 2, lambda: ops.erode(gray, ops.ellipse_se(7))),
+                ("dilate_31", "morph_runs_kernel<true>", 2, lambda: ops.dilate(gray, ops.ellipse_se(31))),
                 ("median_3", "median3_kernel", 2, lambda: ops.median_blur(gray, 3)),
                 ("median_5", "median5_kernel", 2, lambda: ops.median_blur(gray, 5)),
                 ("median_7", "median7_kernel", 2, lambda: ops.median_blur(gray, 7)),

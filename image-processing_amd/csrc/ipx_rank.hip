@@ -316,6 +316,146 @@ __global__ __launch_bounds__(kTileW * kTileH) void morph_kernel(const uint8_t* _
     dst[(int64_t)img * g.d_img + (int64_t)y * g.d_row + x] = (uint8_t)acc;
 }
 
+// ---- erode / dilate with a structuring element larger than 5 x 5: runs and a sparse table ---------------------------------
+// The kernel above visits every member of the element for every pixel: 729 LDS reads for OpenCV's 31 x 31 ellipse.  A row of a
+// structuring element is a few RUNS of members (one per row for every ellipse, rectangle and cross), and the min / max over
+// a run of length L is op(T_p[s], T_p[s + L - p]), p = the largest power of two <= L, where T_p[x] = op over tile[x .. x + p - 1]
+// (the sparse table of range-minimum queries, built by doubling: T_2p[x] = op(T_p[x], T_p[x + p])).  The block stages its tile
+// (pixels outside the image = the neutral value, OpenCV's default morphology border), builds the levels the element needs
+// in LDS, and a pixel then costs two byte reads per run: 62 for the 31 x 31 ellipse.  A thread takes 8 pixels of one
+// column (rows 4 apart): a run's two LDS offsets are formed once and reach the 8 rows through immediate offsets.
+constexpr int kRunW = 64, kRunH = 32, kRunThreads = 256, kRunPx = kRunW * kRunH / kRunThreads;     // 8 pixels per thread
+constexpr int kRunPitch = kRunW + 2 * kMaxR + 18;          // 112: the levels read up to 15 bytes past a tile row
+constexpr int kMaxRuns = 64;
+struct SeRuns {
+    int count, levels, plane;                              // runs; table levels beyond the tile itself (0 .. 4); LDS bytes per level
+    uint16_t off1[kMaxRuns], off2[kMaxRuns];               // LDS byte offsets of the two queries, relative to the pixel's tile origin
+};
+
+template <bool DILATE>
+__global__ __launch_bounds__(kRunThreads) void morph_runs_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, RankGeom g, SeRuns se)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_t[];   // (levels + 1) planes of th x kRunPitch + 16 bytes
+    const unsigned tile = blockIdx.x;
+    const int tx0 = (int)(tile % (unsigned)g.tiles_x) * kRunW;
+    const int ty0 = (int)(tile / (unsigned)g.tiles_x % (unsigned)g.tiles_y) * kRunH;
+    const unsigned img = tile / ((unsigned)g.tiles_x * (unsigned)g.tiles_y);
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    const int tid = (int)threadIdx.x;
+    constexpr uint8_t kNeutral = DILATE ? 0 : 255;
+    auto op = [](uint32_t a, uint32_t b) { return DILATE ? (a > b ? a : b) : (a < b ? a : b); };
+
+    // Staging and the table levels work on dwords: 32 lanes per tile row (28 dwords = 112 bytes = the pitch), 8 rows per pass.
+    const int tw = kRunW + 2 * g.rx, th = kRunH + 2 * g.ry;
+    const int dq = tid & 31, r8 = tid >> 5;
+    const int cx = 4 * dq, gx = tx0 - g.rx + cx;                                 // tile column / image column of this lane's dword
+    if (dq < kRunPitch / 4) {
+#pragma unroll
+        for (int it = 0; it < (kRunH + 2 * kMaxR + 7) / 8; ++it) {               // unrolled: the passes' loads are issued together
+            const int ry = r8 + 8 * it;
+            if (ry >= th) break;
+            const int y = ty0 - g.ry + ry;
+            uint32_t v = kNeutral * 0x01010101u;
+            if (y >= 0 && y < g.h) {
+                const uint8_t* rp = simg + (int64_t)y * g.s_row;
+                if (gx >= 0 && gx + 4 <= g.w && cx + 4 <= tw) {
+                    v = *(const u32_u*)(rp + gx);                                // (unaligned dword loads are fine in global memory)
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int x = gx + j;
+                        if (x >= 0 && x < g.w && cx + j < tw) v = (v & ~(255u << (8 * j))) | ((uint32_t)rp[x] << (8 * j));
+                    }
+                }
+            }
+            *(uint32_t*)(s_t + ry * kRunPitch + cx) = v;
+        }
+    }
+    __syncthreads();
+    // T_(2^l)[x] = op(T_(2^(l-1))[x], T_(2^(l-1))[x + 2^(l-1)]), four entries per lane: the second operand is the dword 1, 2, 4 or 8
+    // bytes on (two aligned reads and a byte alignment for 1 and 2), op on bytes as two packed 16-bit operations.  Entries near a
+    // row's end combine bytes of the next row: they are never queried (a query's range lies inside the tile row).
+    auto op4 = [](uint32_t a, uint32_t b) {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        const uint32_t m = 0x00ff00ffu;
+        const uint32_t ae = a & m, ao = (a >> 8) & m, be = b & m, bo = (b >> 8) & m;
+        us2 e, o;
+        const us2 ae2 = __builtin_bit_cast(us2, ae), be2 = __builtin_bit_cast(us2, be);
+        const us2 ao2 = __builtin_bit_cast(us2, ao), bo2 = __builtin_bit_cast(us2, bo);
+        e = DILATE ? __builtin_elementwise_max(ae2, be2) : __builtin_elementwise_min(ae2, be2);
+        o = DILATE ? __builtin_elementwise_max(ao2, bo2) : __builtin_elementwise_min(ao2, bo2);
+        return __builtin_bit_cast(uint32_t, e) | (__builtin_bit_cast(uint32_t, o) << 8);
+    };
+    for (int l = 1; l <= se.levels; ++l) {
+        const uint8_t* lo = s_t + (l - 1) * se.plane;
+        uint8_t* hi = s_t + l * se.plane;
+        const int step = 1 << (l - 1);
+        if (dq < kRunPitch / 4) {
+            for (int ry = r8; ry < th; ry += 8) {
+                const int a = ry * kRunPitch + cx;
+                const uint32_t v0 = *(const uint32_t*)(lo + a);
+                uint32_t v1;
+                if (step >= 4) {
+                    v1 = *(const uint32_t*)(lo + a + step);
+                } else {
+                    const uint32_t nx = *(const uint32_t*)(lo + a + 4);
+                    v1 = __builtin_amdgcn_alignbyte(nx, v0, (uint32_t)step);
+                }
+                *(uint32_t*)(hi + a) = op4(v0, v1);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int lx = tid % kRunW, ly = tid / kRunW;                                // rows ly, ly + 4, ..., ly + 28
+    const int x = tx0 + lx;
+    if (x >= g.w) return;
+    const uint8_t* base = s_t + ly * kRunPitch + lx;
+    uint32_t acc[kRunPx];
+#pragma unroll
+    for (int i = 0; i < kRunPx; ++i) acc[i] = kNeutral;
+    for (int r = 0; r < se.count; ++r) {
+        const uint8_t* p1 = base + se.off1[r];
+        const uint8_t* p2 = base + se.off2[r];
+#pragma unroll
+        for (int i = 0; i < kRunPx; ++i) acc[i] = op(acc[i], op(p1[i * 4 * kRunPitch], p2[i * 4 * kRunPitch]));
+    }
+    uint8_t* dp = dst + (int64_t)img * g.d_img + x;
+#pragma unroll
+    for (int i = 0; i < kRunPx; ++i) {
+        const int y = ty0 + ly + 4 * i;
+        if (y < g.h) dp[(int64_t)y * g.d_row] = (uint8_t)acc[i];
+    }
+}
+
+// The element's rows as runs; false if it has more than kMaxRuns of them (the kernel above this one then takes it).
+bool make_runs(const SeMask& m, int se_rows, int se_cols, SeRuns* out)
+{
+    SeRuns r{};
+    int maxlen = 1;
+    r.plane = (kRunH + se_rows - 1) * kRunPitch + 16;
+    for (int wy = 0; wy < se_rows; ++wy) {
+        int wx = 0;
+        while (wx < se_cols) {
+            if (!((m.bits[wy] >> wx) & 1u)) { ++wx; continue; }
+            int len = 1;
+            while (wx + len < se_cols && ((m.bits[wy] >> (wx + len)) & 1u)) ++len;
+            if (r.count == kMaxRuns) return false;
+            int lvl = 0;
+            while ((2 << lvl) <= len) ++lvl;                                     // 2^lvl <= len < 2^(lvl + 1)
+            const int o1 = lvl * r.plane + wy * kRunPitch + wx;
+            r.off1[r.count] = (uint16_t)o1;
+            r.off2[r.count] = (uint16_t)(o1 + len - (1 << lvl));
+            ++r.count;
+            if (len > maxlen) maxlen = len;
+            wx += len;
+        }
+    }
+    while ((2 << r.levels) <= maxlen) ++r.levels;
+    *out = r;
+    return true;
+}
+
 int make_geom(const char* fn, RankGeom& g, const uint8_t* src, uint8_t* dst, int n, int h, int w, int rx, int ry,
               int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, unsigned* blocks)
 {
@@ -430,6 +570,18 @@ int ipx_morph_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, i
     if (int rc = ipx_morph_small((hipStream_t)stream, src, dst, n, h, w, src_row_stride, src_img_stride, dst_row_stride, dst_img_stride,
                                  op, se.bits, se_rows, se_cols))
         return rc < 0 ? rc : IPX_OK;
+    SeRuns runs;
+    if (make_runs(se, se_rows, se_cols, &runs)) {                 // rows of few runs (every ellipse, rectangle, cross): sparse-table queries
+        g.tiles_x = (w + kRunW - 1) / kRunW;
+        g.tiles_y = (h + kRunH - 1) / kRunH;
+        const uint64_t nb = (uint64_t)n * g.tiles_x * g.tiles_y;
+        if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: too many tiles", fn);
+        const size_t lds = (size_t)(runs.levels + 1) * runs.plane;              // <= 5 x 6960 bytes
+        if (op) hipLaunchKernelGGL(morph_runs_kernel<true>, dim3((unsigned)nb), dim3(kRunThreads), lds, (hipStream_t)stream, src, dst, g, runs);
+        else hipLaunchKernelGGL(morph_runs_kernel<false>, dim3((unsigned)nb), dim3(kRunThreads), lds, (hipStream_t)stream, src, dst, g, runs);
+        IPX_LAUNCH_CHECK("morph_runs_kernel");
+        return IPX_OK;
+    }
     if (op) hipLaunchKernelGGL(morph_kernel<true>, dim3(blocks), dim3(kTileW * kTileH), 0, (hipStream_t)stream, src, dst, g, se);
     else hipLaunchKernelGGL(morph_kernel<false>, dim3(blocks), dim3(kTileW * kTileH), 0, (hipStream_t)stream, src, dst, g, se);
     IPX_LAUNCH_CHECK("morph_kernel");
