@@ -310,6 +310,41 @@ def test_gaussian(dev, shape, cn, k):
     np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(img, dev), k)), O.gaussian_blur_u8(img, k))
 
 
+@pytest.mark.parametrize("cn", [1, 2, 3, 4])
+def test_kernels_beyond_31_taps_two_pass_dot_product_path(dev, cn):
+    """k > 31 (cv2.GaussianBlur(img, (g, g), 0) with the reference's unclamped `gauss`, server.py:402-409, :428): two passes through
+    a Q8.8 scratch image on v_dot4_u32_u8 / v_dot2_u32_u16.  Images smaller than the radius (REFLECT_101 folds several times),
+    widths around the 1 KiB row chunks and the 64-column tiles, heights around the 64-row tiles, every tap count parity case,
+    a batch, a row-strided view, halo rows, saturated input; and taps that do not fit a byte (the plain two-pass kernels)."""
+    rng = np.random.default_rng(40 + cn)
+    for (h, w), k in (((1, 1), 33), ((3, 5), 35), ((20, 30), 63), ((65, 70), 33), ((64, 1100 // cn), 45), ((130, 257), 101),
+                      ((40, 90), 255), ((129, 64), 127)):
+        img = rng.integers(0, 256, (h, w, cn) if cn > 1 else (h, w), dtype=np.uint8)
+        np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(img, dev), k)), O.gaussian_blur_u8(img, k), err_msg=f"{h}x{w}x{cn} k={k}")
+    full = np.full((70, 300, cn) if cn > 1 else (70, 300), 255, np.uint8)
+    np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(full, dev), 63)), full)
+    batch = rng.integers(0, 256, (3, 80, 333, cn), dtype=np.uint8)
+    view = dev_t(batch, dev)[:, 4:76, 3:320]
+    got = host(ops.gaussian_blur(view, 33))
+    for i in range(3):
+        ref = O.gaussian_blur_u8(np.ascontiguousarray(batch[i, 4:76, 3:320, 0] if cn == 1 else batch[i, 4:76, 3:320]), 33)
+        np.testing.assert_array_equal(got[i].reshape(ref.shape), ref)
+    # a row block with halo rows == the whole-image result cropped
+    tall = rng.integers(0, 256, (150, 200, cn) if cn > 1 else (150, 200), dtype=np.uint8)
+    t = dev_t(tall, dev)
+    r = 16
+    got = host(ops.gaussian_blur(t[40:100], 33, top_halo=t[40 - r:40], bottom_halo=t[100:100 + r]))
+    np.testing.assert_array_equal(got, O.gaussian_blur_u8(tall, 33)[40:100])
+    got = host(ops.gaussian_blur(t[:60], 33, bottom_halo=t[60:60 + r]))
+    np.testing.assert_array_equal(got, O.gaussian_blur_u8(tall, 33)[:60])
+    # taps above 255 cannot go through the byte dot product
+    kx = [0] * 16 + [256] + [0] * 16
+    ky = [1] * 16 + [224] + [1] * 16
+    img = rng.integers(0, 256, (50, 120, cn) if cn > 1 else (50, 120), dtype=np.uint8)
+    np.testing.assert_array_equal(host(ops.sep_filter_q8(dev_t(img, dev), kx, ky)), O.sep_filter_q8_u8(img, np.array(kx), np.array(ky)))
+    np.testing.assert_array_equal(host(ops.sep_filter_q8(dev_t(img, dev), ky, ky[::-1])), O.sep_filter_q8_u8(img, np.array(ky), np.array(ky[::-1])))
+
+
 def test_gaussian_c2_and_asymmetric_taps(dev):
     img = rnd((37, 300, 2), 11)
     np.testing.assert_array_equal(host(ops.gaussian_blur(dev_t(img, dev), 5)), O.gaussian_blur_u8(img, 5))

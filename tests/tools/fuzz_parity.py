@@ -159,8 +159,8 @@ while time.time() < t_end:
             t = buf[:, :, :w * c * 2]
         fails += check(f"gray16.{c}", ops.gray_from_u16(t, w, c, big_endian=be, rgb_order=rgb), O.gray_u8_from_u16_bytes(raw, w, c, be, rgb), (n, h, w, c, be, rgb, strided))
     elif op == "gaussbig":                                   # the generic two-pass path (k > 31)
-        c = int(rng.choice([1, 3]))
-        k = int(rng.choice([33, 45, 63, 101, 255]))
+        c = int(rng.choice([1, 1, 2, 3, 4]))
+        k = int(rng.choice([33, 35, 45, 63, 101, 127, 255]))
         h, w = min(h, 200), min(w, 600)
         t, img = make(n, h, w, c, strided)
         fails += check(f"gauss{k}", ops.gaussian_blur(t, k), per_image(lambda x: O.gaussian_blur_u8(x, k), img), (n, h, w, c, strided))
@@ -178,7 +178,7 @@ while time.time() < t_end:
         # a row block [y0, y1) of a taller image with r halo rows from its neighbours == the whole-image result cropped
         c = int(rng.choice([1, 3]))
         which = str(rng.choice(["sharpen", "box3", "sobel", "gauss"]))
-        k = int(rng.choice([3, 5, 7, 9, 15, 31])) if which == "gauss" else 3
+        k = int(rng.choice([3, 5, 7, 9, 15, 31, 33, 47])) if which == "gauss" else 3
         r = k // 2
         h = max(h, 3 * r + 3)
         t, img = make(1, h, w, c, False)
