@@ -220,6 +220,39 @@ def test_log_tables_built_on_the_device(dev):
             assert (got[top][lv] == want[lv]).all()
 
 
+def test_log_lut_entry_point_strided_output_and_bad_arguments(dev):
+    """ipx_log_lut_u8 through ops.log_lut: tables written with a row stride (one slot of N x k x 256 table sets) equal the
+    contiguous ones and luts.log; the other slots stay untouched; bad arguments are rejected."""
+    import ipx._lib as L
+    rng = np.random.default_rng(5)
+    hists = np.zeros((7, 256), np.int32)
+    for i in range(7):
+        lv = rng.integers(0, 256, rng.integers(1, 6))
+        hists[i, lv] = rng.integers(1, 1000, lv.size)
+    curve = torch.from_numpy(luts.log_curve(2.0)).to(dev)
+    h = dev_t(hists, dev)
+    plain = host(ops.log_lut(h, curve))
+    sets = torch.full((7, 3, 256), 77, dtype=torch.uint8, device=dev)
+    ops.log_lut(h, curve, out=sets[:, 1])
+    got = host(sets)
+    np.testing.assert_array_equal(got[:, 1], plain)
+    assert (got[:, 0] == 77).all() and (got[:, 2] == 77).all()
+    for i in range(7):
+        top = int(np.nonzero(hists[i])[0].max())
+        np.testing.assert_array_equal(plain[i][:top + 1], luts.log(2.0, hists[i])[:top + 1])
+        assert (plain[i][top + 1:] == 255).all()
+    with pytest.raises(ValueError):
+        ops.log_lut(h, curve.double())
+    with pytest.raises(ValueError):
+        ops.log_lut(h, curve, out=torch.empty((7, 128), dtype=torch.uint8, device=dev))
+    with pytest.raises(L.IpxError):
+        L.call("ipx_log_lut_u8", 0, h.data_ptr(), 7, curve.data_ptr(), sets.data_ptr(), 100)
+    with pytest.raises(L.IpxError):
+        L.call("ipx_log_lut_u8", 0, h.data_ptr(), 0, curve.data_ptr(), sets.data_ptr(), 256)
+    with pytest.raises(L.IpxError):
+        L.call("ipx_log_lut_u8", 0, None, 7, curve.data_ptr(), sets.data_ptr(), 256)
+
+
 def test_bgr2gray_hist_without_table_pass(dev):
     """ipx_bgr2gray_equalize_u8 with dst = NULL: gray image, histograms and equalize tables only (the caller applies the tables,
     e.g. in ipx_lut_multi_u8); rejected when no output would take the result."""
