@@ -906,6 +906,18 @@ def test_full_size_rank_and_lee_filters(dev):
     op, cl = ops.morph_open(t, se), ops.morph_close(t, se)
     assert bool((op <= t).all()) and bool((t <= cl).all())
     check(host(op), lambda a: O.morph_open_u8(a, se), 6, True)
+    for msz in (15, 31):                                    # the run / sparse-table kernel at full size
+        seb = ops.ellipse_se(msz)
+        erb, dib = ops.erode(t, seb), ops.dilate(t, seb)
+        assert bool((erb <= er).all()) and bool((di <= dib).all())          # a larger ellipse contains the smaller one
+        check(host(erb), lambda a: O.erode_u8(a, seb), msz // 2, True)
+        check(host(dib), lambda a: O.dilate_u8(a, seb), msz // 2, True)
+    for wnd in (11, 15, 21):                                # the two-pixels-per-thread Lee kernel at full size
+        got = host(ops.lee_filter(t, wnd))
+        check(got, lambda a: O.lee_filter_u8(a, wnd), wnd // 2 + wnd // 2, False)
+    for k in (33, 63):                                      # the dot-product two-pass filters at full size (interior crops: REFLECT_101
+        got = host(ops.gaussian_blur(t, k))                 # at a crop's edge is only right at the image border)
+        check(got, lambda a: O.gaussian_blur_u8(a, k), k // 2, False)
     two = dev_t(img[500:900, 1000:2600], dev)
     m = ops.median_blur(two, 7)
     assert set(torch.unique(m).tolist()) <= {0, 255}
