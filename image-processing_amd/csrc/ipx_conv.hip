@@ -1421,21 +1421,29 @@ __global__ __launch_bounds__(256) void sep_cols_kernel(const uint16_t* __restric
 //                 adjacent values packed two per dword ([column][row pair], an odd pitch: conflict-free for a wave's 64
 //                 columns); an output is then (k + 1) / 2 LDS dword reads and as many v_dot2_u32_u16 against the tap pairs
 //                 (two tables: an odd output row starts in the middle of a pair), rounding constant in the accumulator.
-constexpr int kDotChunk = 1024, kDotMaxM = 256;
+constexpr int kDotChunk = 1024, kDotMaxM = 256, kDotRows = 4;   // a row-pass block: 1 KiB of kDotRows consecutive scratch rows
 struct TapsDot4 { int m; uint32_t w[kDotMaxM]; };          // m dwords of four spread row taps each (zero-padded)
-struct TapsDot2 { uint32_t even[IPX_MAX_GAUSS_K / 2 + 2], odd[IPX_MAX_GAUSS_K / 2 + 2]; };
+// column taps as pairs, three zero pairs on either side: a lane works on FOUR output rows of one parity at once (their windows are
+// one pair apart), so that a window dword is read once and meets the tap pairs m, m - 1, m - 2, m - 3
+constexpr int kDot2Pad = 3;
+struct TapsDot2 { uint32_t even[IPX_MAX_GAUSS_K / 2 + 2 + 2 * kDot2Pad], odd[IPX_MAX_GAUSS_K / 2 + 2 + 2 * kDot2Pad]; };
 
 __global__ __launch_bounds__(256) void sep_rows_dot4_kernel(const uint8_t* __restrict__ src, uint16_t* __restrict__ tmp,
                                                             ConvGeom g, int C, int r, TapsDot4 tp)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dot[];
-    const int trow = blockIdx.y;                              // 0 .. h + 2r - 1
+    const int trow0 = (int)blockIdx.y * kDotRows;             // scratch rows trow0 .. trow0 + kDotRows - 1 of h + 2r
+    const int nrows = g.h + 2 * r;
     const unsigned img = blockIdx.z;
     const int chunk0 = (int)blockIdx.x * kDotChunk;
-    const uint8_t* rp = row_ptr(g, src + (int64_t)img * g.s_img, trow - r, r);
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
     const int tid = (int)threadIdx.x;
     const int tile_bytes = kDotChunk + 4 * tp.m + 4, o = chunk0 - r * C;          // tile byte t is row byte o + t
-    for (int t = 4 * tid; t < tile_bytes; t += 4 * 256) {
+    const int tile_dw = tile_bytes >> 2;
+    for (int i = tid; i < kDotRows * tile_dw; i += 256) {                          // (kDotRows tiles, one after the other in LDS)
+        const int rr = i / tile_dw, t = 4 * (i - rr * tile_dw);
+        const int trow = trow0 + rr < nrows ? trow0 + rr : nrows - 1;
+        const uint8_t* rp = row_ptr(g, simg, trow - r, r);
         const int rb = o + t;
         uint32_t v = 0;
         if (rb >= 0 && rb + 4 <= g.L) {
@@ -1449,29 +1457,39 @@ __global__ __launch_bounds__(256) void sep_rows_dot4_kernel(const uint8_t* __res
                 v |= (uint32_t)rp[reflect101(px, g.w) * C + ch] << (8 * j);
             }
         }
-        *(uint32_t*)(s_dot + t) = v;
+        *(uint32_t*)(s_dot + rr * tile_bytes + t) = v;
     }
     __syncthreads();
     const int off = 4 * tid, b0 = chunk0 + off;
     if (b0 >= g.L) return;
-    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    uint32_t d0 = *(const uint32_t*)(s_dot + off);
-    for (int mi = 0; mi < tp.m; ++mi) {
-        const uint32_t d1 = *(const uint32_t*)(s_dot + off + 4 * mi + 4);
-        const uint32_t w = tp.w[mi];
-        a0 = __builtin_amdgcn_udot4(d0, w, a0, false);
-        a1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1u), w, a1, false);
-        a2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2u), w, a2, false);
-        a3 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3u), w, a3, false);
-        d0 = d1;
+    uint32_t acc[kDotRows][4], d0[kDotRows];
+#pragma unroll
+    for (int rr = 0; rr < kDotRows; ++rr) {
+        acc[rr][0] = acc[rr][1] = acc[rr][2] = acc[rr][3] = 0;
+        d0[rr] = *(const uint32_t*)(s_dot + rr * tile_bytes + off);
     }
-    uint16_t* tp_row = tmp + ((int64_t)img * (g.h + 2 * r) + trow) * (int64_t)g.L + b0;
-    if (b0 + 4 <= g.L) {
-        const u32x2 two = {a0 | (a1 << 16), a2 | (a3 << 16)};
-        __builtin_memcpy(tp_row, &two, 8);
-    } else {
-        const uint32_t a[4] = {a0, a1, a2, a3};
-        for (int i = 0; b0 + i < g.L; ++i) tp_row[i] = (uint16_t)a[i];
+    for (int mi = 0; mi < tp.m; ++mi) {
+        const uint32_t w = tp.w[mi];
+#pragma unroll
+        for (int rr = 0; rr < kDotRows; ++rr) {
+            const uint32_t d1 = *(const uint32_t*)(s_dot + rr * tile_bytes + off + 4 * mi + 4);
+            acc[rr][0] = __builtin_amdgcn_udot4(d0[rr], w, acc[rr][0], false);
+            acc[rr][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0[rr], 1u), w, acc[rr][1], false);
+            acc[rr][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0[rr], 2u), w, acc[rr][2], false);
+            acc[rr][3] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0[rr], 3u), w, acc[rr][3], false);
+            d0[rr] = d1;
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < kDotRows; ++rr) {
+        if (trow0 + rr >= nrows) break;
+        uint16_t* tp_row = tmp + ((int64_t)img * nrows + trow0 + rr) * (int64_t)g.L + b0;
+        if (b0 + 4 <= g.L) {
+            const u32x2 two = {acc[rr][0] | (acc[rr][1] << 16), acc[rr][2] | (acc[rr][3] << 16)};
+            __builtin_memcpy(tp_row, &two, 8);
+        } else {
+            for (int i = 0; b0 + i < g.L; ++i) tp_row[i] = (uint16_t)acc[rr][i];
+        }
     }
 }
 
@@ -1487,10 +1505,12 @@ __global__ __launch_bounds__(256) void sep_cols_dot2_kernel(const uint16_t* __re
     const uint16_t* tb = tmp + ((int64_t)img * (g.h + 2 * r) + y0) * (int64_t)g.L;
     const int tid = (int)threadIdx.x;
     const int npairs = (rows_in + 1) >> 1;
-    for (int i = tid; i < npairs * kColW; i += 256) {
-        const int col = i & (kColW - 1), q = i >> 6;
+    const int col = tid & (kColW - 1);
+    const bool col_in = b0 + col < g.L;
+#pragma unroll 4
+    for (int q = tid >> 6; q < pitch; q += 4) {               // every pair slot of the column is written (zeros past the tile's rows)
         uint32_t lo = 0, hi = 0;
-        if (b0 + col < g.L) {
+        if (col_in && q < npairs) {
             lo = tb[(int64_t)(2 * q) * g.L + b0 + col];
             if (2 * q + 1 < rows_in) hi = tb[(int64_t)(2 * q + 1) * g.L + b0 + col];
         }
@@ -1499,17 +1519,32 @@ __global__ __launch_bounds__(256) void sep_cols_dot2_kernel(const uint16_t* __re
     __syncthreads();
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (b0 + lane >= g.L) return;
+    // wave: output rows of parity (wave & 1) in the tile's upper / lower half; four rows yo, yo + 2, yo + 4, yo + 6 at a time
+    const int par = wave & 1;
+    const uint32_t* taps = (par ? tp.odd : tp.even) + kDot2Pad;                 // taps[-3 .. -1] and taps[r + 1 .. r + 3] are zero
     const uint32_t* mine = s_col + lane * pitch;
     uint8_t* dp = dst + (int64_t)img * g.d_img + b0 + lane;
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    for (int yo = wave; yo < rows_out; yo += 4) {              // (wave-uniform: one tap table per iteration)
-        const uint32_t* taps = (yo & 1) ? tp.odd : tp.even;
-        const uint32_t* win = mine + (yo >> 1);
-        uint32_t acc = 32768u;
-        for (int m = 0; m <= r; ++m)
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, win[m]), __builtin_bit_cast(us2, taps[m]), acc, false);
-        acc >>= 16;
-        dp[(int64_t)(y0 + yo) * g.d_row] = (uint8_t)(acc > 255u ? 255u : acc);
+    for (int q0 = 16 * (wave >> 1); q0 < 16 * (wave >> 1) + 16; q0 += 4) {
+        if (2 * q0 + par >= rows_out) break;                  // (wave-uniform)
+        uint32_t a0 = 32768u, a1 = 32768u, a2 = 32768u, a3 = 32768u;
+        const uint32_t* win = mine + q0;
+        for (int u = 0; u <= r + 3; ++u) {
+            const us2 d = __builtin_bit_cast(us2, win[u]);
+            a0 = __builtin_amdgcn_udot2(d, __builtin_bit_cast(us2, taps[u]), a0, false);
+            a1 = __builtin_amdgcn_udot2(d, __builtin_bit_cast(us2, taps[u - 1]), a1, false);
+            a2 = __builtin_amdgcn_udot2(d, __builtin_bit_cast(us2, taps[u - 2]), a2, false);
+            a3 = __builtin_amdgcn_udot2(d, __builtin_bit_cast(us2, taps[u - 3]), a3, false);
+        }
+        const uint32_t a[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int yo = 2 * (q0 + j) + par;
+            if (yo < rows_out) {
+                const uint32_t v = a[j] >> 16;
+                dp[(int64_t)(y0 + yo) * g.d_row] = (uint8_t)(v > 255u ? 255u : v);
+            }
+        }
     }
 }
 
@@ -2013,15 +2048,15 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
         for (int j = 0; j < k; ++j) t4.w[(j * c) >> 2] |= (uint32_t)kx_q8[j] << (8 * ((j * c) & 3));
         TapsDot2 t2{};
         for (int m = 0; m <= r; ++m) {
-            t2.even[m] = (uint32_t)ky_q8[2 * m] | (2 * m + 1 < k ? (uint32_t)ky_q8[2 * m + 1] << 16 : 0u);
-            t2.odd[m] = (m ? (uint32_t)ky_q8[2 * m - 1] : 0u) | ((uint32_t)ky_q8[2 * m] << 16);
+            t2.even[kDot2Pad + m] = (uint32_t)ky_q8[2 * m] | (2 * m + 1 < k ? (uint32_t)ky_q8[2 * m + 1] << 16 : 0u);
+            t2.odd[kDot2Pad + m] = (m ? (uint32_t)ky_q8[2 * m - 1] : 0u) | ((uint32_t)ky_q8[2 * m] << 16);
         }
-        const size_t lds_rows = (size_t)kDotChunk + 4 * t4.m + 8;
-        hipLaunchKernelGGL(sep_rows_dot4_kernel, dim3((unsigned)((g.L + kDotChunk - 1) / kDotChunk), (unsigned)(h + 2 * r), (unsigned)n), dim3(256),
+        const size_t lds_rows = (size_t)kDotRows * (kDotChunk + 4 * t4.m + 4) + 16;
+        hipLaunchKernelGGL(sep_rows_dot4_kernel, dim3((unsigned)((g.L + kDotChunk - 1) / kDotChunk), (unsigned)((h + 2 * r + kDotRows - 1) / kDotRows), (unsigned)n), dim3(256),
                            lds_rows, st, src, tmp, g, c, r, t4);
         if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "%s: launch of sep_rows_dot4_kernel failed", fn);
         if (rc == IPX_OK) {
-            const int pitch = ((kColH + 2 * r + 1) / 2 + 1) | 1;
+            const int pitch = ((kColH + 2 * r + 1) / 2 + 4) | 1;       // pairs of the tile's rows + the three a four-row group reads beyond
             hipLaunchKernelGGL(sep_cols_dot2_kernel, dim3((unsigned)((g.L + kColW - 1) / kColW), (unsigned)((h + kColH - 1) / kColH), (unsigned)n), dim3(256),
                                (size_t)kColW * pitch * sizeof(uint32_t), st, tmp, dst, g, r, pitch, t2);
             if (hipGetLastError() != hipSuccess) rc = ipx_fail(IPX_ERR_HIP, "%s: launch of sep_cols_dot2_kernel failed", fn);
