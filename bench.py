@@ -5,8 +5,10 @@ Workload at every N (weak scaling, one process per GPU, no data-path collective)
 "3840x2160 RGB image, 5x5 Gaussian + Sobel edge + hist-eq", as a batch of --batch such images already resident
 in HBM.  One step = for every image of the batch:
     gauss5  = cv2.GaussianBlur(bgr,(5,5),0)                 (colour, 6 B/px algorithmic)
-    gray,eq = cv2.cvtColor(bgr, BGR2GRAY); cv2.equalizeHist(gray)   (4 + 2 B/px, one fused entry point)
+    gray,eq = cv2.cvtColor(bgr, BGR2GRAY); cv2.equalizeHist(gray)   (4 + 2 B/px as two calls)
     sobel   = 3x3 Sobel magnitude of gray                   (2 B/px)   <- the "conv3x3" of the metric
+Three launches per step since round 3: the Gaussian; BGR->gray + histogram + equalize tables; Sobel AND equalizeHist's table pass
+on one read of the gray batch (ipx_sobel_lut_u8: 3 B/px instead of 2 + 2).  --order sobel_mid is the four-launch form.
 value = (ranks x batch x 8.2944 MP) / step time: pixels pushed through the whole pipeline per second.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the 5x5 Gaussian) by its algorithmic
@@ -247,10 +249,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=24, help="4K RGB frames per GPU per step (round 2: 8: 353 k, 16: 382 k, 20: 400 k, 24: 408 k, 32: 410 k, 48: 397 k MP/s; beyond 24 frames the gray batch no longer fits the Infinity Cache between the kernels that write and read it)")
     ap.add_argument("--cpu-sample", type=int, default=250, help="passes of the CPU oracle over 4 frames, ~15 s of CPU work, capped at 30 s (0 = skip)")
-    ap.add_argument("--order", default="sobel_mid", choices=["sobel_mid", "table_first", "gauss_last"],
-                    help="order of the step's four launches (same kernels, same results): sobel_mid = Gaussian, BGR->gray+histogram, "
-                         "Sobel, equalize table pass (Sobel reads the gray batch right after it was written); table_first = the "
-                         "round-1 order (equalize finished before Sobel); gauss_last = sobel_mid with the Gaussian at the end")
+    ap.add_argument("--order", default="fused_tail", choices=["fused_tail", "sobel_mid", "table_first", "gauss_last"],
+                    help="the step's launches (same results in every form): fused_tail = Gaussian, BGR->gray+histogram, then Sobel and "
+                         "the equalize table pass on ONE read of the gray batch (ipx_sobel_lut_u8); sobel_mid = the four-launch form of "
+                         "round 2 (Gaussian, BGR->gray+histogram, Sobel, table pass); table_first = the round-1 order (equalize finished "
+                         "before Sobel); gauss_last = sobel_mid with the Gaussian at the end")
     ap.add_argument("--ops-table", action="store_true", help="also time ops that are not part of the step, back to back")
     ap.add_argument("--rank-timeout", type=float, default=420.0, help="--gpus N without a launcher: seconds before silent ranks are stopped")
     ap.add_argument("--workload", default="pipeline", choices=["pipeline", "rowpart"],
@@ -315,9 +318,11 @@ def main():
         ("bgr2gray_hist", "gray_hist_kernel<3>+hist_finish_kernel", 4),      # cvtColor + histogram + equalize table (server.py:245-246, first half)
         ("sobel3_gray", "conv3_kernel<SOBEL,1>", 2),
         ("equalize_table_pass", "lut_kernel", 2),                            # cv2.equalizeHist's second half: dst = table[gray]
+        # Sobel and that table pass on one read of the gray batch: 1 byte read + 2 written per pixel (2 + 2 as two launches)
+        ("sobel3_gray+equalize_table_pass", "conv3_lut_kernel<SOBEL>", 3),
     ]
 
-    ORDERS = {"sobel_mid": (0, 1, 2, 3), "table_first": (0, 1, 3, 2), "gauss_last": (1, 2, 3, 0)}
+    ORDERS = {"fused_tail": (0, 1, 4), "sobel_mid": (0, 1, 2, 3), "table_first": (0, 1, 3, 2), "gauss_last": (1, 2, 3, 0)}
     order = ORDERS[args.order]
     STEP_OPS = [STEP_OPS[i] for i in order]
 
@@ -345,8 +350,10 @@ def main():
                 res["gray"], _, res["lut"] = ops.bgr2gray_hist(src)   # cvtColor, histogram taken while gray is written, equalize tables
             elif i == 2:
                 res["sb"] = ops.sobel(res["gray"])
-            else:
+            elif i == 3:
                 res["eq"] = ops.apply_lut_dev(res["gray"], res["lut"])
+            else:
+                res["sb"], res["eq"] = ops.sobel_lut(res["gray"], res["lut"])
             if ev is not None and only is None:
                 ev[j + 1].record()
             if ev is not None and only == i:
@@ -374,27 +381,27 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     # the same K steps once more, instrumented around every op (outside the timed region): the per-op table
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(len(order) + 1)] for _ in range(args.steps)]
     for i in range(args.steps):
         step(events[i])
     torch.cuda.synchronize()
     # the LITERAL configs[1]: ONE 4K image per launch (what a single /api/process request sees); same event scheme
     one = bgr[:1]
     lat_steps = 50
-    LAT_OPS = ("gaussian5_bgr", "bgr2gray_equalize", "sobel3_gray")
+    LAT_OPS = ("gaussian5_bgr", "bgr2gray_hist", "sobel3_gray+equalize_table_pass")
 
     def step_one(ev=None):
-        """what three single requests do: the Gaussian, the FUSED cvtColor + equalizeHist call, Sobel (with one image per
-        launch the host's enqueue time shows between the events, so the step's four-launch form would only add to it)"""
+        """the step on ONE frame, three launches: the Gaussian; cvtColor + histogram + equalize table (one frame is enough blocks
+        for the table to be built inside the counting launch); Sobel and the table pass on one read of the gray frame"""
         if ev is not None:
             ev[0].record()
         ops.gaussian_blur(one, 5)
         if ev is not None:
             ev[1].record()
-        gray1, _ = ops.bgr2gray_equalize(one)
+        gray1, _, lut1 = ops.bgr2gray_hist(one)
         if ev is not None:
             ev[2].record()
-        ops.sobel(gray1)
+        ops.sobel_lut(gray1, lut1)
         if ev is not None:
             ev[3].record()
 
@@ -474,9 +481,10 @@ def main():
                 s = sum(events[i][j].elapsed_time(events[i][j + 1]) for i in range(args.steps)) / args.steps * 1e-3
                 kernels[name] = row(kern, bpp, s, "HIP events around every op in K instrumented steps after the timed region (in-pipeline)")
         # cvtColor + equalizeHist as ONE op (the round-1 table's key): its two halves added up
-        a, b = kernels["bgr2gray_hist"], kernels["equalize_table_pass"]
-        kernels["bgr2gray_equalize"] = row(a["kernel"] + "+" + b["kernel"], 6, (a["us_per_launch"] + b["us_per_launch"]) * 1e-6,
-                                           "sum of bgr2gray_hist and equalize_table_pass above")
+        if "equalize_table_pass" in kernels:
+            a, b = kernels["bgr2gray_hist"], kernels["equalize_table_pass"]
+            kernels["bgr2gray_equalize"] = row(a["kernel"] + "+" + b["kernel"], 6, (a["us_per_launch"] + b["us_per_launch"]) * 1e-6,
+                                               "sum of bgr2gray_hist and equalize_table_pass above")
         latency_b1_us = {}
         for j, name in enumerate(LAT_OPS):
             ts = sorted(lat_events[i][j].elapsed_time(lat_events[i][j + 1]) for i in range(lat_steps))

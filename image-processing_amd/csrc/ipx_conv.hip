@@ -284,6 +284,96 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void conv3_kernel(const uin
     }
 }
 
+// The same walker with a SECOND output from the same read: dst2 = table[src] (per-image tables in device memory).  A batch
+// pipeline that wants a 3 x 3 operator AND a pixel-wise table pass of one gray batch -- BASELINE.json configs[1]: Sobel of the
+// gray image and cv2.equalizeHist's table pass, server.py:246 -- reads the batch once: 1 + 2 bytes per pixel instead of 2 + 2.
+// Every source row of a wave's segment passes through its window registers exactly once (plus the segment's two halo rows,
+// which belong to the neighbouring segments and are skipped): its 16 bytes go through the table (per-wave copy in LDS) there.
+__device__ __forceinline__ uint32_t conv_lut4(const uint8_t* sl, uint32_t x)
+{
+    return (uint32_t)sl[x & 255u] | ((uint32_t)sl[(x >> 8) & 255u] << 8) |
+           ((uint32_t)sl[(x >> 16) & 255u] << 16) | ((uint32_t)sl[x >> 24] << 24);
+}
+
+template <int OP>
+__global__ __launch_bounds__(64 * kMaxWavesPerBlock) void conv3_lut_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                           uint8_t* __restrict__ dst2, ConvGeom g,
+                                                                           const uint8_t* __restrict__ lut_dev, int64_t lut_stride)
+{
+    constexpr int C = 1;
+    __shared__ uint32_t s_lut[kMaxWavesPerBlock][64];
+    if (blockIdx.x >= g.main_blocks) {                       // ---- border bytes, one per thread (rows shorter than 44 bytes)
+        unsigned img; int y, b;
+        if (!border_item(g, blockIdx.x - g.main_blocks, img, y, b)) return;
+        const uint8_t* simg = src + (int64_t)img * g.s_img;
+        const int xl = reflect101(b - 1, g.w), xr = reflect101(b + 1, g.w);
+        const uint8_t* rc = row_ptr(g, simg, y, 1);
+        dst[(int64_t)img * g.d_img + (int64_t)y * g.d_row + b] = (uint8_t)conv3_byte<OP>(
+            row_ptr(g, simg, y - 1, 1), rc, row_ptr(g, simg, y + 1, 1), xl, b, xr);
+        dst2[(int64_t)img * g.d_img + (int64_t)y * g.d_row + b] = lut_dev[(int64_t)img * lut_stride + rc[b]];
+        return;
+    }
+    unsigned img; int y0, y1, lane0;
+    if (!wave_item(g, img, y0, y1, lane0)) return;
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {
+        uint32_t v;
+        __builtin_memcpy(&v, lut_dev + (int64_t)img * lut_stride + 4 * lane, 4);
+        s_lut[wave][lane] = v;                               // this wave's image's table; only this wave reads it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const uint8_t* sl = reinterpret_cast<const uint8_t*>(s_lut[wave]);
+    const int gl = lane0 + lane;                             // 16-byte lane of the row
+    if (gl >= g.nlanes) return;
+    const int b0 = lane_b0(g, gl);
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const uint8_t* simg = src + (int64_t)img * g.s_img;
+    uint8_t* dimg = dst + (int64_t)img * g.d_img;
+    uint8_t* d2img = dst2 + (int64_t)img * g.d_img;
+    typedef Win<C, 1> W1;
+    typedef Conv3<OP, C> Op;
+    constexpr int U = kConv3U;                               // rows per step; loads run one step ahead
+    const int nrows = y1 - y0;
+    auto row = [&](int t) {                                  // t-th source row of the walk, t = 0 .. nrows + 1
+        return row_ptr(g, simg, y0 + (t <= nrows + 1 ? t : nrows + 1) - 1, 1);
+    };
+    auto table_pass = [&](const W1& wv, int y) {             // the window's own 16 bytes (image row y) through the table
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = conv_lut4(sl, wv.w[W1::HD + k]);
+        st16_nt(d2img + (int64_t)y * g.d_row + b0, o);
+    };
+    typename Op::Feat fa, fb;
+    {
+        W1 wa, wb;
+        load_win<C, 1>(wa, row(0), b0, g.L);
+        load_win<C, 1>(wb, row(1), b0, g.L);
+        table_pass(wb, y0);
+        fix_edges<C, 1>(wa, first, last);
+        fix_edges<C, 1>(wb, first, last);
+        Op::feat(fa, wa);
+        Op::feat(fb, wb);
+    }
+    W1 nx[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) load_win<C, 1>(nx[j], row(2 + j), b0, g.L);
+    for (int i = 0; i < nrows; i += U) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            typename Op::Feat fc;
+            if (i + j + 1 < nrows) table_pass(nx[j], y0 + i + j + 1);   // nx[j] holds image row y0 + i + j + 1
+            fix_edges<C, 1>(nx[j], first, last);
+            Op::feat(fc, nx[j]);
+            load_win<C, 1>(nx[j], row(i + U + 2 + j), b0, g.L);    // the slot is free: refill it with the row U steps further on
+            if (i + j < nrows) st16_nt(dimg + (int64_t)(y0 + i + j) * g.d_row + b0, Op::out(fa, fb, fc));
+            fa = fb;
+            fb = fc;
+        }
+    }
+}
+
 // ---- separable fixed-point filter, K <= 7, register sliding window ---------------------------------------
 // Column pass on ROW PAIRS: the Q8.8 row results of source rows (2p, 2p+1) of the walk are re-packed (2 v_perm per
 // slot) into registers that hold the SAME column of both rows, so that one v_dot2_u32_u16 applies two taps.  The two
@@ -1949,6 +2039,23 @@ int ipx_sobel_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, i
                  const uint8_t* top_halo, const uint8_t* bottom_halo)
 {
     return launch_conv3<OP_SOBEL>("ipx_sobel_u8", stream, src, dst, n, h, w, c, s_row, s_img, d_row, d_img, top_halo, bottom_halo);
+}
+
+int ipx_sobel_lut_u8(void* stream, const uint8_t* src, uint8_t* dst_sobel, uint8_t* dst_lut, int n, int h, int w,
+                     int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* lut_dev, int64_t lut_stride)
+{
+    const char* fn = "ipx_sobel_lut_u8";
+    ipx_clear_error();
+    if (!lut_dev) return ipx_fail(IPX_ERR_INVALID, "%s: null table", fn);
+    if (lut_stride != 0 && lut_stride < 256) return ipx_fail(IPX_ERR_INVALID, "%s: lut_stride %lld must be 0 or >= 256", fn, (long long)lut_stride);
+    if (int rc = ipx_check_image_args(fn, src, dst_lut, n, h, w, 1, 1, s_row, s_img, d_row, d_img)) return rc;
+    if (dst_lut == dst_sobel) return ipx_fail(IPX_ERR_INVALID, "%s: the two destinations are the same buffer", fn);
+    ConvGeom g;
+    if (int rc = make_conv_geom(fn, g, src, dst_sobel, n, h, w, 1, 1, kMaxWavesPerBlock, kConv3U, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
+    hipLaunchKernelGGL((conv3_lut_kernel<OP_SOBEL>), dim3(conv_grid(g)), dim3(conv_block(g)), 0, (hipStream_t)stream, src, dst_sobel, dst_lut, g,
+                       lut_dev, lut_stride);
+    IPX_LAUNCH_CHECK("conv3_lut_kernel");
+    return IPX_OK;
 }
 
 int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "ipx_laplacian_sharpen_u8": (_i, _IMG + [_i] + _STR + [_vp, _vp]),
     "ipx_box3_u8": (_i, _IMG + [_i] + _STR + [_vp, _vp]),
     "ipx_sobel_u8": (_i, _IMG + [_i] + _STR + [_vp, _vp]),
+    "ipx_sobel_lut_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i] + _STR + [_vp, _i64]),
     "ipx_gauss_kernel_q8": (_i, [_i, C.c_double, _vp]),
     "ipx_sep_filter_q8_u8": (_i, _IMG + [_i] + _STR + [_vp, _vp, _i, _vp, _vp]),
     "ipx_gaussian_blur_u8": (_i, _IMG + [_i] + _STR + [_i, _vp, _vp]),

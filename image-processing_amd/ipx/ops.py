@@ -399,6 +399,22 @@ def sobel(src, top_halo=None, bottom_halo=None):
     return _conv3("ipx_sobel_u8", src, top_halo, bottom_halo)
 
 
+def sobel_lut(src: torch.Tensor, luts: torch.Tensor):
+    """sobel(src) and apply_lut_dev(src, luts) of one gray batch in one pass over it (ipx_sobel_lut_u8): returns
+    (sobel, table[src]).  luts: (256,) shared or (N,256) per image, uint8 on the device."""
+    s = _gray(src)
+    if luts.dtype != torch.uint8 or luts.device != s.t.device or luts.shape[-1] != 256:
+        raise ValueError("luts: uint8 tensor (..., 256) on the image's device expected")
+    l2 = luts.reshape(-1, 256).contiguous()
+    if l2.shape[0] not in (1, s.n):
+        raise ValueError(f"luts: {l2.shape[0]} tables for {s.n} images")
+    with _OnDevice(s.t.device):
+        a, b = s.like(), s.like()
+        _lib.call("ipx_sobel_lut_u8", _stream(), s.ptr, a.data_ptr(), b.data_ptr(), s.n, s.h, s.w,
+                  s.row, s.img, s.w, s.w * s.h, l2.data_ptr(), 256 if l2.shape[0] > 1 else 0)
+    return s.restore(a), s.restore(b)
+
+
 def gauss_kernel_q8(k: int, sigma: float = 0.0) -> np.ndarray:
     """Q0.8 taps cv2.GaussianBlur uses on uint8 (library helper, host side)."""
     if k < 1 or k % 2 == 0 or k > _lib.MAX_GAUSS_K:

@@ -76,12 +76,13 @@ def full_pipeline(ops, bgr) -> dict:
 
 def configs1_step(ops, bgr):
     """BASELINE.json configs[1]: 5x5 Gaussian (BGR) + hist-eq (incl. BGR->gray) + Sobel on the gray image.  cvtColor +
-    equalizeHist run as the fused entry point's two halves with Sobel between them: Sobel then reads the gray batch right
-    after it was written (same kernels and results as bgr2gray_equalize followed by sobel, 2.5 % less time per step)."""
+    equalizeHist run as the fused entry point's first half (gray batch, histograms, tables); Sobel and equalizeHist's table
+    pass then share ONE read of the gray batch (ipx_sobel_lut_u8), right after it was written: same pixels as
+    bgr2gray_equalize followed by sobel, 5 % less time per step than the four-launch form (scripts/dev/sobellut.py)."""
     g5 = ops.gaussian_blur(bgr, 5)
     gray, _, lut = ops.bgr2gray_hist(bgr)
-    sb = ops.sobel(gray)
-    return g5, ops.apply_lut_dev(gray, lut), sb
+    sb, eq = ops.sobel_lut(gray, lut)
+    return g5, eq, sb
 
 
 def configs1_one_image(ops, bgr, side_stream=None):
@@ -98,8 +99,8 @@ def configs1_one_image(ops, bgr, side_stream=None):
         side_stream.wait_stream(cur)
         with torch.cuda.stream(side_stream):
             g5 = ops.gaussian_blur(bgr, 5)
-    gray, eq = ops.bgr2gray_equalize(bgr)
-    sb = ops.sobel(gray)
+    gray, _, lut = ops.bgr2gray_hist(bgr)                        # gray, histogram, table (one launch for one 4K frame)
+    sb, eq = ops.sobel_lut(gray, lut)                            # Sobel + the table pass on one read of the gray frame
     if side_stream is not None:
         torch.cuda.current_stream().wait_stream(side_stream)
     return g5, gray, eq, sb

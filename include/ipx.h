@@ -215,6 +215,16 @@ int ipx_sobel_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, i
                  int64_t dst_row_stride, int64_t dst_img_stride,
                  const uint8_t* top_halo, const uint8_t* bottom_halo);
 
+/* ipx_sobel_u8 AND ipx_lut_dev_u8 of the same gray batch in one pass: dst_sobel = Sobel magnitude of src (as above),
+ * dst_lut = table_i[src] with image i's 256-byte table at lut_dev + i*lut_stride (DEVICE memory; lut_stride 0 = one shared
+ * table) -- e.g. the second half of cv2.equalizeHist, server.py:246, with the tables ipx_bgr2gray_equalize_u8 (dst = NULL)
+ * produced.  The source is read once: 1 + 2 bytes per pixel instead of 2 + 2 (BASELINE.json configs[1] runs both on the gray
+ * image).  Gray images (one channel); both destinations have the dst strides and must not overlap src or each other. */
+int ipx_sobel_lut_u8(void* stream, const uint8_t* src, uint8_t* dst_sobel, uint8_t* dst_lut, int n, int h, int w,
+                     int64_t src_row_stride, int64_t src_img_stride,
+                     int64_t dst_row_stride, int64_t dst_img_stride,
+                     const uint8_t* lut_dev, int64_t lut_stride);
+
 /* ---- separable Gaussian ------------------------------------------------------------------- */
 
 /* Host helper: the Q0.8 kernel cv2.GaussianBlur(img,(k,k),sigma) uses on uint8 input (fixed tables

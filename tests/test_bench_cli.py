@@ -34,8 +34,15 @@ def test_gpus_2_starts_two_ranks(dev):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["batch_per_gpu"] == 4 and j["value"] > 0
     assert j["scaling"] == "weak" and j["cpu_baseline"] is None
-    assert set(j["latency_b1_us"]) >= {"gaussian5_bgr", "bgr2gray_equalize", "sobel3_gray", "step"}
-    assert set(j["kernels"]) >= {"gaussian5_bgr", "bgr2gray_hist", "equalize_table_pass", "bgr2gray_equalize", "sobel3_gray"}
+    assert set(j["latency_b1_us"]) >= {"gaussian5_bgr", "bgr2gray_hist", "sobel3_gray+equalize_table_pass", "step"}
+    assert set(j["kernels"]) >= {"gaussian5_bgr", "bgr2gray_hist", "sobel3_gray+equalize_table_pass"}
+    assert j["config"]["launch_order"] == ["gaussian5_bgr", "bgr2gray_hist", "sobel3_gray+equalize_table_pass"]
+    # the four-launch form of round 2 stays available
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--cpu-sample", "0", "--order", "sobel_mid"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    j4 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert set(j4["kernels"]) >= {"gaussian5_bgr", "bgr2gray_hist", "equalize_table_pass", "bgr2gray_equalize", "sobel3_gray"}
 
 
 def test_a_rank_that_dies_before_the_rendezvous_ends_the_run_quickly():

@@ -325,6 +325,41 @@ def test_conv3(dev, shape, cn, name, ref):
     np.testing.assert_array_equal(got, ref(img))
 
 
+def test_sobel_and_table_pass_in_one_read(dev):
+    """ipx_sobel_lut_u8: Sobel and a per-image table pass of one gray batch in one launch == the two separate entry points
+    == the oracle; rows shorter than the walker's 44 bytes (per-byte blocks), ragged widths, 1 KiB strip edges, segment
+    edges, a batch with per-image tables, a shared table, a row-strided view; bad arguments."""
+    import ipx._lib as L
+    rng = np.random.default_rng(123)
+    for h, w in ((1, 1), (2, 3), (5, 43), (7, 44), (9, 45), (33, 1023), (40, 1024), (41, 1025), (130, 2051), (300, 700), (64, 4096)):
+        for n in (1, 3):
+            img = rng.integers(0, 256, (n, h, w, 1), dtype=np.uint8)
+            tabs = np.stack([rng.permutation(256).astype(np.uint8) for _ in range(n)])
+            sb, tb = ops.sobel_lut(dev_t(img, dev), dev_t(tabs, dev))
+            for i in range(n):
+                np.testing.assert_array_equal(host(sb)[i, :, :, 0], O.sobel_u8(img[i, :, :, 0]), err_msg=f"sobel {n}x{h}x{w}")
+                np.testing.assert_array_equal(host(tb)[i, :, :, 0], tabs[i][img[i, :, :, 0]], err_msg=f"table {n}x{h}x{w}")
+    img = rng.integers(0, 256, (2, 90, 1500), dtype=np.uint8)
+    one = rng.permutation(256).astype(np.uint8)
+    view = dev_t(img, dev)[:, 5:85, 7:1400].unsqueeze(-1)
+    sb, tb = ops.sobel_lut(view, dev_t(one, dev))
+    for i in range(2):
+        crop = np.ascontiguousarray(img[i, 5:85, 7:1400])
+        np.testing.assert_array_equal(host(sb)[i, :, :, 0], O.sobel_u8(crop))
+        np.testing.assert_array_equal(host(tb)[i, :, :, 0], one[crop])
+    g2 = dev_t(img[0], dev)
+    s1, t1 = ops.sobel_lut(g2, dev_t(one, dev))
+    np.testing.assert_array_equal(host(s1), host(ops.sobel(g2)))
+    np.testing.assert_array_equal(host(t1), host(ops.apply_lut(g2, one)))
+    with pytest.raises(ValueError):
+        ops.sobel_lut(g2, dev_t(np.zeros((3, 256), np.uint8), dev))
+    out = torch.empty_like(g2)
+    with pytest.raises(L.IpxError):
+        L.call("ipx_sobel_lut_u8", 0, g2.data_ptr(), out.data_ptr(), out.data_ptr(), 1, 90, 1500, 1500, 0, 1500, 0, dev_t(one, dev).data_ptr(), 0)
+    with pytest.raises(L.IpxError):
+        L.call("ipx_sobel_lut_u8", 0, g2.data_ptr(), out.data_ptr(), torch.empty_like(g2).data_ptr(), 1, 90, 1500, 1500, 0, 1500, 0, None, 0)
+
+
 @pytest.mark.parametrize("name,ref", CONV)
 def test_conv3_extremes(dev, name, ref):
     """saturating inputs: checkerboards of 0/255 hit both clamps of sharpen and the 255 cap of Sobel."""
