@@ -7,8 +7,10 @@ in HBM.  One step = for every image of the batch:
     gauss5  = cv2.GaussianBlur(bgr,(5,5),0)                 (colour, 6 B/px algorithmic)
     gray,eq = cv2.cvtColor(bgr, BGR2GRAY); cv2.equalizeHist(gray)   (4 + 2 B/px as two calls)
     sobel   = 3x3 Sobel magnitude of gray                   (2 B/px)   <- the "conv3x3" of the metric
-Three launches per step since round 3: the Gaussian; BGR->gray + histogram + equalize tables; Sobel AND equalizeHist's table pass
-on one read of the gray batch (ipx_sobel_lut_u8: 3 B/px instead of 2 + 2).  --order sobel_mid is the four-launch form.
+Three launches per step since round 3, each input read once: the Gaussian AND the gray image from one read of the colour batch
+(ipx_gaussian_blur_gray_u8: 3 read + 3 + 1 written per pixel); the gray batch's histograms + equalize tables (1 read); Sobel AND
+equalizeHist's table pass on one read of the gray batch (ipx_sobel_lut_u8: 1 read + 2 written) = 11 B/px instead of 14.
+--order fused_tail keeps the colour batch's two readers apart, --order sobel_mid is round 2's four-launch form.
 value = (ranks x batch x 8.2944 MP) / step time: pixels pushed through the whole pipeline per second.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the 5x5 Gaussian) by its algorithmic
@@ -249,9 +251,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=24, help="4K RGB frames per GPU per step (round 2: 8: 353 k, 16: 382 k, 20: 400 k, 24: 408 k, 32: 410 k, 48: 397 k MP/s; beyond 24 frames the gray batch no longer fits the Infinity Cache between the kernels that write and read it)")
     ap.add_argument("--cpu-sample", type=int, default=250, help="passes of the CPU oracle over 4 frames, ~15 s of CPU work, capped at 30 s (0 = skip)")
-    ap.add_argument("--order", default="fused_tail", choices=["fused_tail", "sobel_mid", "table_first", "gauss_last"],
-                    help="the step's launches (same results in every form): fused_tail = Gaussian, BGR->gray+histogram, then Sobel and "
-                         "the equalize table pass on ONE read of the gray batch (ipx_sobel_lut_u8); sobel_mid = the four-launch form of "
+    ap.add_argument("--order", default="fused", choices=["fused", "fused_tail", "sobel_mid", "table_first", "gauss_last"],
+                    help="the step's launches (same results in every form): fused = Gaussian AND gray from one read of the colour batch "
+                         "(ipx_gaussian_blur_gray_u8), histograms + tables of the gray batch, then Sobel and the equalize table pass on "
+                         "ONE read of the gray batch (ipx_sobel_lut_u8); fused_tail = Gaussian, BGR->gray+histogram, Sobel + table pass; sobel_mid = the four-launch form of "
                          "round 2 (Gaussian, BGR->gray+histogram, Sobel, table pass); table_first = the round-1 order (equalize finished "
                          "before Sobel); gauss_last = sobel_mid with the Gaussian at the end")
     ap.add_argument("--ops-table", action="store_true", help="also time ops that are not part of the step, back to back")
@@ -320,13 +323,16 @@ def main():
         ("equalize_table_pass", "lut_kernel", 2),                            # cv2.equalizeHist's second half: dst = table[gray]
         # Sobel and that table pass on one read of the gray batch: 1 byte read + 2 written per pixel (2 + 2 as two launches)
         ("sobel3_gray+equalize_table_pass", "conv3_lut_kernel<SOBEL>", 3),
+        # the Gaussian and cvtColor on one read of the colour batch: 3 bytes read, 3 + 1 written per pixel (6 + 4 as two launches)
+        ("gaussian5_bgr+bgr2gray", "sep_pow2_band_gray_kernel<5>", 7),
+        ("hist_tables_gray", "hist_partial_kernel+hist_finish_kernel", 1),   # histograms + equalize tables of the gray batch (1 byte read)
     ]
 
-    ORDERS = {"fused_tail": (0, 1, 4), "sobel_mid": (0, 1, 2, 3), "table_first": (0, 1, 3, 2), "gauss_last": (1, 2, 3, 0)}
+    ORDERS = {"fused": (5, 6, 4), "fused_tail": (0, 1, 4), "sobel_mid": (0, 1, 2, 3), "table_first": (0, 1, 3, 2), "gauss_last": (1, 2, 3, 0)}
     order = ORDERS[args.order]
     STEP_OPS = [STEP_OPS[i] for i in order]
 
-    DOMINANT = 0                                                  # index into the unordered op list: the 5x5 Gaussian
+    DOMINANT = 5 if 5 in order else 0                             # index into the unordered op list: the launch that holds the 5x5 Gaussian
 
     def step(ev=None, only=None, src=None):
         """One pass of the pipeline over the resident batch; `ev` (optional) receives HIP events at op boundaries,
@@ -352,8 +358,12 @@ def main():
                 res["sb"] = ops.sobel(res["gray"])
             elif i == 3:
                 res["eq"] = ops.apply_lut_dev(res["gray"], res["lut"])
-            else:
+            elif i == 4:
                 res["sb"], res["eq"] = ops.sobel_lut(res["gray"], res["lut"])
+            elif i == 5:
+                res["g5"], res["gray"] = ops.gaussian_blur_gray(src, 5)
+            else:
+                _, res["lut"] = ops.hist_tables(res["gray"])
             if ev is not None and only is None:
                 ev[j + 1].record()
             if ev is not None and only == i:
@@ -388,17 +398,18 @@ def main():
     # the LITERAL configs[1]: ONE 4K image per launch (what a single /api/process request sees); same event scheme
     one = bgr[:1]
     lat_steps = 50
-    LAT_OPS = ("gaussian5_bgr", "bgr2gray_hist", "sobel3_gray+equalize_table_pass")
+    LAT_OPS = ("gaussian5_bgr+bgr2gray", "hist_tables_gray", "sobel3_gray+equalize_table_pass")
 
     def step_one(ev=None):
-        """the step on ONE frame, three launches: the Gaussian; cvtColor + histogram + equalize table (one frame is enough blocks
-        for the table to be built inside the counting launch); Sobel and the table pass on one read of the gray frame"""
+        """the step on ONE frame, three launches: the Gaussian and the gray frame from one read of the colour frame; the gray
+        frame's histogram + equalize table (one frame is enough blocks for the table to be built inside the counting launch);
+        Sobel and the table pass on one read of the gray frame"""
         if ev is not None:
             ev[0].record()
-        ops.gaussian_blur(one, 5)
+        _, gray1 = ops.gaussian_blur_gray(one, 5)
         if ev is not None:
             ev[1].record()
-        gray1, _, lut1 = ops.bgr2gray_hist(one)
+        _, lut1 = ops.hist_tables(gray1)
         if ev is not None:
             ev[2].record()
         ops.sobel_lut(gray1, lut1)
@@ -481,7 +492,7 @@ def main():
                 s = sum(events[i][j].elapsed_time(events[i][j + 1]) for i in range(args.steps)) / args.steps * 1e-3
                 kernels[name] = row(kern, bpp, s, "HIP events around every op in K instrumented steps after the timed region (in-pipeline)")
         # cvtColor + equalizeHist as ONE op (the round-1 table's key): its two halves added up
-        if "equalize_table_pass" in kernels:
+        if "equalize_table_pass" in kernels and "bgr2gray_hist" in kernels:
             a, b = kernels["bgr2gray_hist"], kernels["equalize_table_pass"]
             kernels["bgr2gray_equalize"] = row(a["kernel"] + "+" + b["kernel"], 6, (a["us_per_launch"] + b["us_per_launch"]) * 1e-6,
                                                "sum of bgr2gray_hist and equalize_table_pass above")

@@ -752,6 +752,98 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
     }
 }
 
+// The packed Gaussian on BGR band tiles with a SECOND output from the same tile: the gray image, cv2.cvtColor(BGR2GRAY).
+// BASELINE.json configs[1] blurs the colour frame and converts it to gray (for Sobel and equalizeHist): both read the whole
+// colour batch, 30 % of the step's bytes.  The tile is in LDS anyway: before the filter walk, the block converts the pixels of
+// its 8 output rows whose first byte lies in the tile's own byte range -- groups of 8 pixels = 24 tile bytes (8-byte aligned in
+// LDS; a group reaches at most 23 bytes into the 32-byte halo), three ds_read_b64, a pixel's three bytes as one dword by
+// v_alignbyte_b32 and the Q15 sum as two byte dot products (3735 = 14 * 256 + 151, 19235 = 75 * 256 + 35, 9798 = 38 * 256 + 70:
+// exact), one 8-byte store per group.  A lane takes one group column through the tile's rows (dealing the (group, row) items
+// over all lanes of the block instead measured slower: 306 against 294 us per 24 x 4K).
+struct GrayOut { uint8_t* p; int64_t row, img; };
+
+template <int K>
+__global__ __launch_bounds__(kBandLanes) void sep_pow2_band_gray_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                        BandGeom bg, Pow2Taps t, GrayOut gr)
+{
+    constexpr int C = 3, R = K / 2;
+    typedef Win<C, R> WR;
+    constexpr int HD = WR::HD;
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];
+    const ConvGeom& g = bg.g;
+    const BandTile bt = band_stage<R>(bg, src, s_tile);
+    const int nrows = bt.y1 - bt.y0;
+    {   // ---- gray pixels of the tile's own byte range, rows y0 .. y1 - 1 (tile rows R ..)
+        const int own0 = 16 * bt.lane0;
+        const int own1 = 16 * (bt.lane0 + bg.tile_lanes) < g.L ? 16 * (bt.lane0 + bg.tile_lanes) : g.L;
+        const int j0 = (own0 + 23) / 24, j1 = (own1 + 23) / 24;               // groups whose first byte 24 j lies in [own0, own1)
+        const int jj = j0 + (int)threadIdx.x;
+        if (jj < j1) {
+            const int px0 = 8 * jj;
+            const uint8_t* tp = s_tile + R * bg.pitch + (24 * jj - bt.xs);
+            uint8_t* gp = gr.p + (int64_t)bt.img * gr.img + (int64_t)bt.y0 * gr.row + px0;
+            const uint32_t clo = 151u | (35u << 8) | (70u << 16), chi = 14u | (75u << 8) | (38u << 16);   // B, G, R
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {                                     // (band tiles are 8 output rows; unrolled: the rows' LDS reads overlap)
+                if (r >= nrows) break;
+                const u32x2 q0 = *(const u32x2*)(tp), q1 = *(const u32x2*)(tp + 8), q2 = *(const u32x2*)(tp + 16);
+                const uint32_t d[6] = {q0[0], q0[1], q1[0], q1[1], q2[0], q2[1]};
+                uint32_t y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = (3 * i) >> 2, sh = (3 * i) & 3;
+                    const uint32_t px = sh == 0 ? d[k] : __builtin_amdgcn_alignbyte(d[k + 1 < 6 ? k + 1 : 5], d[k], (uint32_t)sh);
+                    const uint32_t lo = __builtin_amdgcn_udot4(px, clo, 16384u, false);
+                    const uint32_t hi = __builtin_amdgcn_udot4(px, chi, 0u, false);
+                    y[i] = ((hi << 8) + lo) >> 15;
+                }
+                const u32x2 o = {y[0] | (y[1] << 8) | (y[2] << 16) | (y[3] << 24), y[4] | (y[5] << 8) | (y[6] << 16) | (y[7] << 24)};
+                if (px0 + 8 <= g.w) {
+                    __builtin_nontemporal_store(o, (u32x2_u*)gp);
+                } else {
+                    for (int i = 0; px0 + i < g.w; ++i) gp[i] = (uint8_t)y[i];
+                }
+                tp += bg.pitch;
+                gp += gr.row;
+            }
+        }
+    }
+    const int gl = bt.lane0 + (int)threadIdx.x;
+    if ((int)threadIdx.x >= bg.tile_lanes || gl >= g.nlanes) return;
+    const int b0 = 16 * gl;
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const int off = b0 - bt.xs;
+    const int lo = (b0 >= 4 * HD ? b0 - 4 * HD : b0) - bt.xs;
+    const int hi = (b0 + 16 + 4 * HD <= g.L ? b0 + 16 : b0 + 16 - 4 * HD) - bt.xs;
+    uint8_t* dimg = dst + (int64_t)bt.img * g.d_img;
+    const unsigned short kx1 = (unsigned short)t.kx1, kx2 = (unsigned short)t.kx2;
+    const unsigned short ky1 = (unsigned short)t.ky1, ky2 = (unsigned short)t.ky2;
+    const us2 rnd = {(unsigned short)t.rnd, (unsigned short)t.rnd};
+    const us2 sh = {(unsigned short)t.sh, (unsigned short)t.sh};
+    us2 hb[K][8];
+    auto hrow = [&](us2 (&h)[8], int r) {                                    // row pass of tile row r
+        WR W;
+        band_win<C, R>(W, s_tile, bg.pitch, r, off, lo, hi);
+        fix_edges<C, R>(W, first, last);
+        pow2_rowpass<C, K>(h, W, kx1, kx2);
+    };
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) hrow(hb[j], j);
+    for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += K) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const int tt = t0 + q;
+            const int slot = (K - 1 + q) % K;                                // = tt % K
+            const int yo = tt - (K - 1);
+            if (yo < nrows) {
+                hrow(hb[slot], tt);
+                const u32x4 ov = pow2_colpass<K>(hb, slot, ky1, ky2, rnd, sh);
+                st16_nt(dimg + (int64_t)(bt.y0 + yo) * g.d_row + b0, ov);
+            }
+        }
+    }
+}
+
 // The 3 x 3 operators on the same band tiles (sharpen / box / Sobel on BGR frames: rows of >= 4 KiB).
 template <int OP, int C>
 __global__ __launch_bounds__(kBandLanes) void conv3_band_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, BandGeom bg)
@@ -2183,6 +2275,35 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     hipError_t e = hipFreeAsync(tmp, st);
     if (e != hipSuccess && rc == IPX_OK) rc = ipx_fail(IPX_ERR_HIP, "%s: hipFreeAsync failed: %s", fn, hipGetErrorString(e));
     return rc;
+}
+
+int ipx_gaussian_blur_gray_u8(void* stream, const uint8_t* src, uint8_t* dst, uint8_t* gray, int n, int h, int w,
+                              int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
+                              int64_t gray_row_stride, int64_t gray_img_stride, int k)
+{
+    const char* fn = "ipx_gaussian_blur_gray_u8";
+    ipx_clear_error();
+    if (int rc = ipx_check_image_args(fn, src, gray, n, h, w, 3, 1, s_row, s_img, gray_row_stride, gray_img_stride)) return rc;
+    uint16_t q[IPX_MAX_GAUSS_K];
+    if (int rc = ipx_gauss_kernel_q8(k, 0.0, q)) return rc;
+    ConvGeom g;
+    Pow2Taps pt;
+    if ((k == 3 || k == 5) && pow2_symmetric_taps(q, q, k, &pt)) {
+        if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, 3, k / 2, kMaxWavesPerBlock, k + 1, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
+        const int ntx = (g.nlanes + kBandLanes - 1) / kBandLanes;
+        if (g.L % 16 == 0 && g.nlanes >= 256 && (k == 3 || (g.nlanes + ntx - 1) / ntx >= 224)) {   // the shapes whose Gaussian takes band tiles
+            BandGeom bg;
+            if (int rc = make_band_geom(bg, g, n, 8)) return rc;
+            const GrayOut go{gray, gray_row_stride, gray_img_stride};
+            if (k == 3) launch_band<sep_pow2_band_gray_kernel<3>>((hipStream_t)stream, bg, 1, src, dst, pt, go);
+            else launch_band<sep_pow2_band_gray_kernel<5>>((hipStream_t)stream, bg, 2, src, dst, pt, go);
+            IPX_LAUNCH_CHECK("sep_pow2_band_gray_kernel");
+            return IPX_OK;
+        }
+    }
+    // every other shape or kernel size: the two entry points one after the other
+    if (int rc = ipx_gaussian_blur_u8(stream, src, dst, n, h, w, 3, s_row, s_img, d_row, d_img, k, nullptr, nullptr)) return rc;
+    return ipx_bgr2gray_u8(stream, src, gray, n, h, w, 3, s_row, s_img, gray_row_stride, gray_img_stride);
 }
 
 int ipx_gaussian_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,

@@ -493,6 +493,7 @@ int equalize_with_workspace(hipStream_t st, const uint8_t* src, uint8_t* dst, in
     workspace_layout(n, h, w, &ws, workspace);
     uint8_t* lut = lut_out_dev ? lut_out_dev : ws.lut;
     if (int rc = launch_hist(st, src, n, h, w, s_row, s_img, ws, hist_out_dev, lut)) return rc;
+    if (!dst) return IPX_OK;                                // histograms and tables only: the caller applies the tables
     // the table pass (default cache policy up to kNtHistThenLut bytes: what the histogram pass read is still in the Infinity Cache)
     return ipx_lut_dev_u8((void*)st, src, dst, n, h, w, 1, s_row, s_img, d_row, d_img, lut, 256);
 }
@@ -648,8 +649,12 @@ int ipx_equalize_hist_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
                          int64_t src_row_stride, int64_t src_img_stride, int64_t dst_row_stride, int64_t dst_img_stride,
                          uint32_t* hist_out_dev, uint8_t* lut_out_dev, void* workspace, size_t workspace_bytes)
 {
-    if (int rc = ipx_check_image_args("ipx_equalize_hist_u8", src, dst, n, h, w, 1, 1, src_row_stride, src_img_stride,
-                                      dst_row_stride, dst_img_stride)) return rc;
+    if (!dst) {                                             // tables only (the table pass is the caller's, e.g. ipx_sobel_lut_u8)
+        ipx_clear_error();
+        if (!hist_out_dev && !lut_out_dev) return ipx_fail(IPX_ERR_INVALID, "ipx_equalize_hist_u8: dst = NULL needs hist_out_dev or lut_out_dev");
+        if (!src) return ipx_fail(IPX_ERR_INVALID, "ipx_equalize_hist_u8: null image pointer");
+    } else if (int rc = ipx_check_image_args("ipx_equalize_hist_u8", src, dst, n, h, w, 1, 1, src_row_stride, src_img_stride,
+                                             dst_row_stride, dst_img_stride)) return rc;
     if (int rc = check_hist_args("ipx_equalize_hist_u8", src, n, h, w, src_row_stride, src_img_stride)) return rc;
     hipStream_t st = (hipStream_t)stream;
     void* own = nullptr;

@@ -354,6 +354,19 @@ def bgr2gray_equalize(src: torch.Tensor, return_aux: bool = False):
     return (gray, out, hst, lut) if return_aux else (gray, out)
 
 
+def hist_tables(src: torch.Tensor):
+    """Histograms and cv2.equalizeHist tables of a gray batch without the table pass (ipx_equalize_hist_u8 with dst = NULL):
+    returns (hist int32 (N,256), tables uint8 (N,256)); (256,) each for a single H x W image."""
+    s = _gray(src)
+    with _OnDevice(s.t.device):
+        h = torch.empty((s.n, 256), dtype=torch.int32, device=s.t.device)
+        lut = torch.empty((s.n, 256), dtype=torch.uint8, device=s.t.device)
+        ws = _workspace(s)
+        _lib.call("ipx_equalize_hist_u8", _stream(), s.ptr, None, s.n, s.h, s.w, s.row, s.img, 0, 0,
+                  h.data_ptr(), lut.data_ptr(), ws.data_ptr(), ws.numel())
+    return (h[0], lut[0]) if src.ndim == 2 else (h, lut)
+
+
 def bgr2gray_hist(src: torch.Tensor):
     """cvtColor(BGR2GRAY) + per-image histogram + equalizeHist TABLE in one pass over the colour source, without applying
     the table (ipx_bgr2gray_equalize_u8 with dst = NULL): returns (gray, hist (N x 256 int32), lut (N x 256 uint8))."""
@@ -454,6 +467,19 @@ def gaussian_blur(src, k: int, top_halo=None, bottom_halo=None) -> torch.Tensor:
 
 
 # ---- Lee filter, denoise_manual statistics -------------------------------
+def gaussian_blur_gray(src: torch.Tensor, k: int):
+    """gaussian_blur(src, k) and bgr2gray(src) of one BGR batch in one pass over it (ipx_gaussian_blur_gray_u8): returns
+    (blurred colour batch, gray of the unblurred source)."""
+    s = _Img(src)
+    if s.c != 3:
+        raise ValueError("gaussian_blur_gray needs 3 (BGR) channels")
+    with _OnDevice(s.t.device):
+        out, gray = s.like(), s.like(1)
+        _lib.call("ipx_gaussian_blur_gray_u8", _stream(), s.ptr, out.data_ptr(), gray.data_ptr(), s.n, s.h, s.w,
+                  s.row, s.img, s.w * 3, s.w * 3 * s.h, s.w, s.w * s.h, int(k))
+    return s.restore(out), (gray[0, :, :, 0] if src.ndim == 3 else gray)
+
+
 def lee_filter(src: torch.Tensor, window_size: int = 5) -> torch.Tensor:
     """lee_filter(img, window_size) (server.py:711-732): float32 window mean/variance blend on interior pixels."""
     s = _gray(src)

@@ -75,12 +75,13 @@ def full_pipeline(ops, bgr) -> dict:
 
 
 def configs1_step(ops, bgr):
-    """BASELINE.json configs[1]: 5x5 Gaussian (BGR) + hist-eq (incl. BGR->gray) + Sobel on the gray image.  cvtColor +
-    equalizeHist run as the fused entry point's first half (gray batch, histograms, tables); Sobel and equalizeHist's table
-    pass then share ONE read of the gray batch (ipx_sobel_lut_u8), right after it was written: same pixels as
-    bgr2gray_equalize followed by sobel, 5 % less time per step than the four-launch form (scripts/dev/sobellut.py)."""
-    g5 = ops.gaussian_blur(bgr, 5)
-    gray, _, lut = ops.bgr2gray_hist(bgr)
+    """BASELINE.json configs[1]: 5x5 Gaussian (BGR) + hist-eq (incl. BGR->gray) + Sobel on the gray image, every input read
+    once: the Gaussian and cvtColor share one read of the colour batch (ipx_gaussian_blur_gray_u8), the gray batch's
+    histograms and equalize tables come from one read of it, Sobel and equalizeHist's table pass share the next
+    (ipx_sobel_lut_u8).  Same pixels as gaussian_blur, bgr2gray_equalize and sobel called one after the other; 11 instead of
+    14 bytes per pixel (scripts/dev/gaussgray.py, sobellut.py)."""
+    g5, gray = ops.gaussian_blur_gray(bgr, 5)
+    _, lut = ops.hist_tables(gray)
     sb, eq = ops.sobel_lut(gray, lut)
     return g5, eq, sb
 
@@ -93,13 +94,14 @@ def configs1_one_image(ops, bgr, side_stream=None):
     during each kernel's ramp and tail, and under graph capture the fork becomes two branches that overlap."""
     import torch
     if side_stream is None:
-        g5 = ops.gaussian_blur(bgr, 5)
-    else:
+        g5, gray = ops.gaussian_blur_gray(bgr, 5)                # the Gaussian and the gray frame from one read of the colour frame
+        _, lut = ops.hist_tables(gray)                           # histogram + table (one launch for one 4K frame)
+    else:                                                        # forked form: the Gaussian alone on the side stream
         cur = torch.cuda.current_stream()
         side_stream.wait_stream(cur)
         with torch.cuda.stream(side_stream):
             g5 = ops.gaussian_blur(bgr, 5)
-    gray, _, lut = ops.bgr2gray_hist(bgr)                        # gray, histogram, table (one launch for one 4K frame)
+        gray, _, lut = ops.bgr2gray_hist(bgr)
     sb, eq = ops.sobel_lut(gray, lut)                            # Sobel + the table pass on one read of the gray frame
     if side_stream is not None:
         torch.cuda.current_stream().wait_stream(side_stream)

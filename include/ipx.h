@@ -153,7 +153,9 @@ int ipx_equalize_lut_u8(void* stream, const uint32_t* hist_dev, int n, uint8_t* 
 int ipx_log_lut_u8(void* stream, const uint32_t* hist_dev, int n, const float* curve_dev, uint8_t* lut_dev, int64_t lut_stride);
 
 /* cv2.equalizeHist(img) -- server.py:246.  hist_out_dev (n*256 uint32) and lut_out_dev (n*256 uint8)
- * may be NULL; when given they receive the histogram and table that were used. */
+ * may be NULL; when given they receive the histogram and table that were used.  dst may be NULL: the table pass is then
+ * skipped (histograms and tables only; hist_out_dev or lut_out_dev must be given) for callers that apply the tables
+ * themselves, e.g. together with Sobel in ipx_sobel_lut_u8. */
 int ipx_equalize_hist_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w,
                          int64_t src_row_stride, int64_t src_img_stride,
                          int64_t dst_row_stride, int64_t dst_img_stride,
@@ -247,6 +249,17 @@ int ipx_gaussian_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
                          int64_t src_row_stride, int64_t src_img_stride,
                          int64_t dst_row_stride, int64_t dst_img_stride, int k,
                          const uint8_t* top_halo, const uint8_t* bottom_halo);
+
+/* cv2.GaussianBlur(img, (k,k), 0) -- server.py:428 -- AND cv2.cvtColor(img, COLOR_BGR2GRAY) -- server.py:517 -- of the same
+ * BGR batch in one pass: dst = the blurred colour image (n x h x w x 3), gray = the gray image of the UNBLURRED source
+ * (n x h x w), exactly as the two entry points produce them.  For pipelines that need both from one colour batch
+ * (BASELINE.json configs[1]: 5x5 Gaussian of the frame; Sobel and equalizeHist of its gray image): the colour source is
+ * read once.  One launch for k = 3 and 5 on rows of whole 16-byte lanes that are at least 4 KiB long (4K / 8K frames);
+ * every other case runs the two entry points one after the other.  No halo rows. */
+int ipx_gaussian_blur_gray_u8(void* stream, const uint8_t* src, uint8_t* dst, uint8_t* gray, int n, int h, int w,
+                              int64_t src_row_stride, int64_t src_img_stride,
+                              int64_t dst_row_stride, int64_t dst_img_stride,
+                              int64_t gray_row_stride, int64_t gray_img_stride, int k);
 
 /* ---- speckle filter ---------------------------------------- */
 

@@ -34,9 +34,10 @@ def test_gpus_2_starts_two_ranks(dev):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["batch_per_gpu"] == 4 and j["value"] > 0
     assert j["scaling"] == "weak" and j["cpu_baseline"] is None
-    assert set(j["latency_b1_us"]) >= {"gaussian5_bgr", "bgr2gray_hist", "sobel3_gray+equalize_table_pass", "step"}
-    assert set(j["kernels"]) >= {"gaussian5_bgr", "bgr2gray_hist", "sobel3_gray+equalize_table_pass"}
-    assert j["config"]["launch_order"] == ["gaussian5_bgr", "bgr2gray_hist", "sobel3_gray+equalize_table_pass"]
+    assert set(j["latency_b1_us"]) >= {"gaussian5_bgr+bgr2gray", "hist_tables_gray", "sobel3_gray+equalize_table_pass", "step"}
+    assert set(j["kernels"]) >= {"gaussian5_bgr+bgr2gray", "hist_tables_gray", "sobel3_gray+equalize_table_pass"}
+    assert j["config"]["launch_order"] == ["gaussian5_bgr+bgr2gray", "hist_tables_gray", "sobel3_gray+equalize_table_pass"]
+    assert j["roofline"]["op"] == "gaussian5_bgr+bgr2gray"
     # the four-launch form of round 2 stays available
     r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--cpu-sample", "0", "--order", "sobel_mid"],
                        env=env, capture_output=True, text=True, timeout=300)

@@ -325,6 +325,52 @@ def test_conv3(dev, shape, cn, name, ref):
     np.testing.assert_array_equal(got, ref(img))
 
 
+def test_gaussian_and_gray_in_one_read(dev):
+    """ipx_gaussian_blur_gray_u8: the blurred colour batch and the gray image of the unblurred source from one read == the two
+    entry points == the oracle.  Shapes that take the one-launch band-tile form (rows of whole 16-byte lanes >= 4 KiB: widths
+    1366 (one tile, 4098 bytes -> not a lane multiple: two calls), 1376, 2048, 2752, 3840 px; heights around the 8-row
+    tiles; pixel groups that straddle tile edges), shapes that fall back to the two calls, k = 3 / 5 / 7, a batch, a row-strided view."""
+    rng = np.random.default_rng(321)
+    for (h, w), k in (((9, 1376), 5), ((17, 2048), 5), ((8, 2752), 5), ((23, 3840), 5), ((16, 1376), 3), ((33, 4112), 3), ((7, 7680), 5),
+                      ((20, 1366), 5), ((12, 300), 5), ((40, 2048), 7), ((5, 1), 3)):
+        for n in (1, 2):
+            img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+            g5, gray = ops.gaussian_blur_gray(dev_t(img, dev), k)
+            for i in range(n):
+                np.testing.assert_array_equal(host(g5)[i], O.gaussian_blur_u8(img[i], k), err_msg=f"gauss {n}x{h}x{w} k={k}")
+                np.testing.assert_array_equal(host(gray)[i, :, :, 0], O.bgr2gray_u8(img[i]), err_msg=f"gray {n}x{h}x{w} k={k}")
+    sat = np.zeros((16, 1376, 3), np.uint8); sat[..., 1] = 255; sat[:, ::2] = 255
+    g5, gray = ops.gaussian_blur_gray(dev_t(sat, dev), 5)
+    np.testing.assert_array_equal(host(gray), O.bgr2gray_u8(sat))
+    np.testing.assert_array_equal(host(g5), O.gaussian_blur_u8(sat, 5))
+    big = rng.integers(0, 256, (2, 40, 1500 * 3 + 48), dtype=np.uint8)
+    view = dev_t(big, dev)[:, 3:37, 48:48 + 1376 * 3].unflatten(2, (1376, 3))
+    ref = big[:, 3:37, 48:48 + 1376 * 3].reshape(2, 34, 1376, 3)
+    g5, gray = ops.gaussian_blur_gray(view, 5)
+    for i in range(2):
+        np.testing.assert_array_equal(host(g5)[i], O.gaussian_blur_u8(np.ascontiguousarray(ref[i]), 5))
+        np.testing.assert_array_equal(host(gray)[i, :, :, 0], O.bgr2gray_u8(np.ascontiguousarray(ref[i])))
+    with pytest.raises(ValueError):
+        ops.gaussian_blur_gray(dev_t(rng.integers(0, 256, (8, 64), dtype=np.uint8), dev), 5)
+
+
+def test_hist_tables_without_table_pass(dev):
+    """ipx_equalize_hist_u8 with dst = NULL (ops.hist_tables): histograms and equalize tables only, small images (separate
+    finish) and images of 65+ blocks (finish inside the counting launch); rejected when no output would take the result."""
+    import ipx._lib as L
+    rng = np.random.default_rng(322)
+    for shape in ((1, 5, 7), (3, 40, 333), (2, 1200, 2100)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        hst, lut = ops.hist_tables(dev_t(img[..., None], dev))
+        for i in range(shape[0]):
+            want = np.bincount(img[i].ravel(), minlength=256)
+            np.testing.assert_array_equal(host(hst)[i], want)
+            np.testing.assert_array_equal(host(lut)[i], O.equalize_lut_from_hist(want))
+    t = dev_t(rng.integers(0, 256, (8, 8), dtype=np.uint8), dev)
+    with pytest.raises(L.IpxError):
+        L.call("ipx_equalize_hist_u8", 0, t.data_ptr(), None, 1, 8, 8, 8, 64, 0, 0, None, None, None, 0)
+
+
 def test_sobel_and_table_pass_in_one_read(dev):
     """ipx_sobel_lut_u8: Sobel and a per-image table pass of one gray batch in one launch == the two separate entry points
     == the oracle; rows shorter than the walker's 44 bytes (per-byte blocks), ragged widths, 1 KiB strip edges, segment
