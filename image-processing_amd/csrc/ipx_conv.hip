@@ -754,7 +754,8 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
 
 // The packed Gaussian on BGR band tiles with a SECOND output from the same tile: the gray image, cv2.cvtColor(BGR2GRAY).
 // BASELINE.json configs[1] blurs the colour frame and converts it to gray (for Sobel and equalizeHist): both read the whole
-// colour batch, 30 % of the step's bytes.  The tile is in LDS anyway: before the filter walk, the block converts the pixels of
+// colour batch, 30 % of the step's bytes.  The tile is in LDS anyway: after the filter walk (before it: 294 against 290 us per
+// 24 x 4K), the block converts the pixels of
 // its 8 output rows whose first byte lies in the tile's own byte range -- groups of 8 pixels = 24 tile bytes (8-byte aligned in
 // LDS; a group reaches at most 23 bytes into the 32-byte halo), three ds_read_b64, a pixel's three bytes as one dword by
 // v_alignbyte_b32 and the Q15 sum as two byte dot products (3735 = 14 * 256 + 151, 19235 = 75 * 256 + 35, 9798 = 38 * 256 + 70:
@@ -773,6 +774,41 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_gray_kernel(const ui
     const ConvGeom& g = bg.g;
     const BandTile bt = band_stage<R>(bg, src, s_tile);
     const int nrows = bt.y1 - bt.y0;
+    const int gl = bt.lane0 + (int)threadIdx.x;
+    if (!((int)threadIdx.x >= bg.tile_lanes || gl >= g.nlanes)) {
+    const int b0 = 16 * gl;
+    const bool first = b0 == 0, last = b0 + 16 == g.L;
+    const int off = b0 - bt.xs;
+    const int lo = (b0 >= 4 * HD ? b0 - 4 * HD : b0) - bt.xs;
+    const int hi = (b0 + 16 + 4 * HD <= g.L ? b0 + 16 : b0 + 16 - 4 * HD) - bt.xs;
+    uint8_t* dimg = dst + (int64_t)bt.img * g.d_img;
+    const unsigned short kx1 = (unsigned short)t.kx1, kx2 = (unsigned short)t.kx2;
+    const unsigned short ky1 = (unsigned short)t.ky1, ky2 = (unsigned short)t.ky2;
+    const us2 rnd = {(unsigned short)t.rnd, (unsigned short)t.rnd};
+    const us2 sh = {(unsigned short)t.sh, (unsigned short)t.sh};
+    us2 hb[K][8];
+    auto hrow = [&](us2 (&h)[8], int r) {                                    // row pass of tile row r
+        WR W;
+        band_win<C, R>(W, s_tile, bg.pitch, r, off, lo, hi);
+        fix_edges<C, R>(W, first, last);
+        pow2_rowpass<C, K>(h, W, kx1, kx2);
+    };
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) hrow(hb[j], j);
+    for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += K) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            const int tt = t0 + q;
+            const int slot = (K - 1 + q) % K;                                // = tt % K
+            const int yo = tt - (K - 1);
+            if (yo < nrows) {
+                hrow(hb[slot], tt);
+                const u32x4 ov = pow2_colpass<K>(hb, slot, ky1, ky2, rnd, sh);
+                st16_nt(dimg + (int64_t)(bt.y0 + yo) * g.d_row + b0, ov);
+            }
+        }
+    }
+    }
     {   // ---- gray pixels of the tile's own byte range, rows y0 .. y1 - 1 (tile rows R ..)
         const int own0 = 16 * bt.lane0;
         const int own1 = 16 * (bt.lane0 + bg.tile_lanes) < g.L ? 16 * (bt.lane0 + bg.tile_lanes) : g.L;
@@ -805,40 +841,6 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_gray_kernel(const ui
                 }
                 tp += bg.pitch;
                 gp += gr.row;
-            }
-        }
-    }
-    const int gl = bt.lane0 + (int)threadIdx.x;
-    if ((int)threadIdx.x >= bg.tile_lanes || gl >= g.nlanes) return;
-    const int b0 = 16 * gl;
-    const bool first = b0 == 0, last = b0 + 16 == g.L;
-    const int off = b0 - bt.xs;
-    const int lo = (b0 >= 4 * HD ? b0 - 4 * HD : b0) - bt.xs;
-    const int hi = (b0 + 16 + 4 * HD <= g.L ? b0 + 16 : b0 + 16 - 4 * HD) - bt.xs;
-    uint8_t* dimg = dst + (int64_t)bt.img * g.d_img;
-    const unsigned short kx1 = (unsigned short)t.kx1, kx2 = (unsigned short)t.kx2;
-    const unsigned short ky1 = (unsigned short)t.ky1, ky2 = (unsigned short)t.ky2;
-    const us2 rnd = {(unsigned short)t.rnd, (unsigned short)t.rnd};
-    const us2 sh = {(unsigned short)t.sh, (unsigned short)t.sh};
-    us2 hb[K][8];
-    auto hrow = [&](us2 (&h)[8], int r) {                                    // row pass of tile row r
-        WR W;
-        band_win<C, R>(W, s_tile, bg.pitch, r, off, lo, hi);
-        fix_edges<C, R>(W, first, last);
-        pow2_rowpass<C, K>(h, W, kx1, kx2);
-    };
-#pragma unroll
-    for (int j = 0; j < K - 1; ++j) hrow(hb[j], j);
-    for (int t0 = K - 1; t0 - (K - 1) < nrows; t0 += K) {
-#pragma unroll
-        for (int q = 0; q < K; ++q) {
-            const int tt = t0 + q;
-            const int slot = (K - 1 + q) % K;                                // = tt % K
-            const int yo = tt - (K - 1);
-            if (yo < nrows) {
-                hrow(hb[slot], tt);
-                const u32x4 ov = pow2_colpass<K>(hb, slot, ky1, ky2, rnd, sh);
-                st16_nt(dimg + (int64_t)(bt.y0 + yo) * g.d_row + b0, ov);
             }
         }
     }

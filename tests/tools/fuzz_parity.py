@@ -22,7 +22,7 @@ from ipx import ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=90)
 ap.add_argument("--seed", type=int, default=0)
-ap.add_argument("--ops", default="gray,lut,eq,grayeq,sharpen,box3,sobel,gauss,gauss,lee,median,morph,halo,stats,png,gray16")
+ap.add_argument("--ops", default="gray,lut,eq,grayeq,sharpen,box3,sobel,gauss,gauss,lee,median,morph,halo,stats,png,gray16,gaussgray,sobellut")
 ap.add_argument("--big", action="store_true", help="images of up to ~3 MP and 3000 rows (slower oracle, fewer cases)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
@@ -158,6 +158,23 @@ while time.time() < t_end:
             buf[:, :, :w * c * 2] = t
             t = buf[:, :, :w * c * 2]
         fails += check(f"gray16.{c}", ops.gray_from_u16(t, w, c, big_endian=be, rgb_order=rgb), O.gray_u8_from_u16_bytes(raw, w, c, be, rgb), (n, h, w, c, be, rgb, strided))
+    elif op == "gaussgray":                                  # Gaussian + gray on one read of a BGR batch (band-tile shapes and fall-backs)
+        k = int(rng.choice([3, 5, 5, 5, 7]))
+        w = int(rng.choice([1366, 1376, 1392, 2048, 2064, 2752, 3840, 4112])) if rng.random() < 0.7 else max(1, min(w, 1500))
+        h = int(rng.integers(1, 40))
+        t, img = make(n, h, w, 3, strided)
+        g5, gray = ops.gaussian_blur_gray(t, k)
+        fails += check(f"gaussgray{k}.blur", g5, per_image(lambda x: CO.gaussian_blur_u8(x, k), img), (n, h, w, strided))
+        fails += check(f"gaussgray{k}.gray", gray, per_image(CO.bgr2gray_u8, img), (n, h, w, strided))
+    elif op == "sobellut":                                   # Sobel + per-image table pass on one read of a gray batch
+        t, img = make(n, h, w, 1, strided)
+        tabs = np.stack([rng.permutation(256).astype(np.uint8) for _ in range(n)])
+        sb, tb = ops.sobel_lut(t, torch.from_numpy(tabs).to(dev))
+        fails += check(op + ".sobel", sb, per_image(O.sobel_u8, img), (n, h, w, strided))
+        fails += check(op + ".table", tb, np.stack([tabs[i][img[i]] for i in range(n)]), (n, h, w, strided))
+        hst, lut = ops.hist_tables(t)
+        want = np.stack([O.equalize_lut_from_hist(np.bincount(img[i].ravel(), minlength=256)) for i in range(n)])
+        fails += check(op + ".tables", lut, want, (n, h, w, strided))
     elif op == "gaussbig":                                   # the generic two-pass path (k > 31)
         c = int(rng.choice([1, 1, 2, 3, 4]))
         k = int(rng.choice([33, 35, 45, 63, 101, 127, 255]))
