@@ -25,7 +25,7 @@ tr = glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv"))
 if tr:
     by = collections.defaultdict(list)
     for r in csv.DictReader(open(tr[0])):
-        by[short(r["Kernel_Name"])].append((int(r["Grid_Size_X"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+        by[short(r["Kernel_Name"])].append((int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y") or 1) * int(r.get("Grid_Size_Z") or 1), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     for k, v in by.items():
         gmax = max(g for g, _ in v)
         d = sorted(t for g, t in v if g == gmax)
@@ -77,6 +77,8 @@ for k, c in sorted(pmc.items()):
     rd, wr = 2 * c["FETCH_SIZE"] * 1024 / 1e6, c["WRITE_SIZE"] * 1024 / 1e6
     a = alg.get(k)
     amb = px * a / 1e6 if a else None
+    if amb and rd + wr < 0.5 * amb:            # this run only launched the kernel on one frame (the latency section): no batch figures
+        a = amb = None
     lines.append(f"| `{k}` | {us:.1f} | {rd:.1f} | {wr:.1f} | {rd + wr:.1f} | " +
                  (f"{amb:.1f} | {(rd + wr) / amb:.3f} | {amb / us * 1e3:.0f} | {amb / us * 1e3 / 8000:.3f} |" if a else "- | - | - | - |"))
     traffic_json[k] = int((rd + wr) * 1e6)
