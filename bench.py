@@ -517,7 +517,13 @@ def main():
             for _ in range(40):        # the one-image launches above leave the chip idle: its first measurements afterwards read
                 step()                 # 10-20 % high (clocks), so bring it back to the timed region's state first
             torch.cuda.synchronize()
+            # two non-uniform distributions for hist-eq -- every pixel in one bin (the worst case for LDS
+            # atomics that collide) and low contrast, clip(N(128, 10))
+            gray_const = torch.full_like(gray, 77)
+            gray_low = torch.empty(gray.shape, dtype=torch.float32, device=gray.device).normal_(128.0, 10.0).clamp_(0, 255).to(torch.uint8)
             for name, kern, bpp, fn in [
+                ("equalize_hist_gray_one_bin", "hist_partial_kernel+hist_finish_kernel+lut_kernel", 2, lambda: ops.equalize_hist(gray_const)),
+                ("equalize_hist_gray_low_contrast", "hist_partial_kernel+hist_finish_kernel+lut_kernel", 2, lambda: ops.equalize_hist(gray_low)),
                 ("gaussian5_bgr_b2b", "sep_pow2_band_kernel<3,5>", 6, lambda: ops.gaussian_blur(bgr, 5)),
                 ("bgr2gray", "gray_kernel<3,false>", 4, lambda: ops.bgr2gray(bgr)),
                 ("sobel3_gray_b2b", "conv3_kernel<SOBEL,1>", 2, lambda: ops.sobel(gray)),

@@ -2279,6 +2279,20 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     return rc;
 }
 
+// the shapes and kernel sizes ipx_gaussian_blur_gray_u8 serves with ONE launch (rows of whole 16-byte lanes, >= 4 KiB; a row's band
+// tiles at least 224 lanes wide for 5 taps): the rule of ipx_sep_filter_q8_u8's own choice of band tiles for a BGR batch
+static bool gaussian_gray_one_pass(int w, int k)
+{
+    if (k != 3 && k != 5) return false;
+    const int64_t L = 3ll * w;
+    if (w <= 0 || L > (1 << 30) || L % 16 != 0) return false;
+    const int nlanes = (int)(L / 16);
+    const int ntx = (nlanes + kBandLanes - 1) / kBandLanes;
+    return nlanes >= 256 && (k == 3 || (nlanes + ntx - 1) / ntx >= 224);
+}
+
+int ipx_gaussian_blur_gray_one_pass(int h, int w, int k) { return h > 0 && gaussian_gray_one_pass(w, k) ? 1 : 0; }
+
 int ipx_gaussian_blur_gray_u8(void* stream, const uint8_t* src, uint8_t* dst, uint8_t* gray, int n, int h, int w,
                               int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
                               int64_t gray_row_stride, int64_t gray_img_stride, int k)
@@ -2292,8 +2306,7 @@ int ipx_gaussian_blur_gray_u8(void* stream, const uint8_t* src, uint8_t* dst, ui
     Pow2Taps pt;
     if ((k == 3 || k == 5) && pow2_symmetric_taps(q, q, k, &pt)) {
         if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, 3, k / 2, kMaxWavesPerBlock, k + 1, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
-        const int ntx = (g.nlanes + kBandLanes - 1) / kBandLanes;
-        if (g.L % 16 == 0 && g.nlanes >= 256 && (k == 3 || (g.nlanes + ntx - 1) / ntx >= 224)) {   // the shapes whose Gaussian takes band tiles
+        if (gaussian_gray_one_pass(w, k)) {
             BandGeom bg;
             if (int rc = make_band_geom(bg, g, n, 8)) return rc;
             const GrayOut go{gray, gray_row_stride, gray_img_stride};

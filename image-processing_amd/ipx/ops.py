@@ -467,6 +467,11 @@ def gaussian_blur(src, k: int, top_halo=None, bottom_halo=None) -> torch.Tensor:
 
 
 # ---- Lee filter, denoise_manual statistics -------------------------------
+def gaussian_blur_gray_one_pass(h: int, w: int, k: int) -> bool:
+    """True if gaussian_blur_gray serves h x w BGR images with one launch (one read of the colour batch)."""
+    return bool(_lib.load().ipx_gaussian_blur_gray_one_pass(int(h), int(w), int(k)))
+
+
 def gaussian_blur_gray(src: torch.Tensor, k: int):
     """gaussian_blur(src, k) and bgr2gray(src) of one BGR batch in one pass over it (ipx_gaussian_blur_gray_u8): returns
     (blurred colour batch, gray of the unblurred source)."""

@@ -79,9 +79,15 @@ def configs1_step(ops, bgr):
     once: the Gaussian and cvtColor share one read of the colour batch (ipx_gaussian_blur_gray_u8), the gray batch's
     histograms and equalize tables come from one read of it, Sobel and equalizeHist's table pass share the next
     (ipx_sobel_lut_u8).  Same pixels as gaussian_blur, bgr2gray_equalize and sobel called one after the other; 11 instead of
-    14 bytes per pixel (scripts/dev/gaussgray.py, sobellut.py)."""
-    g5, gray = ops.gaussian_blur_gray(bgr, 5)
-    _, lut = ops.hist_tables(gray)
+    14 bytes per pixel (scripts/dev/gaussgray.py, sobellut.py).  Frames whose rows the one-pass kernel does not take (1080p; rows that
+    are not whole 16-byte lanes) keep the Gaussian alone and cvtColor + histogram + tables as one launch (13 bytes per pixel)."""
+    one_pass = getattr(ops, "gaussian_blur_gray_one_pass", None)
+    if one_pass is not None and one_pass(bgr.shape[-3], bgr.shape[-2], 5):
+        g5, gray = ops.gaussian_blur_gray(bgr, 5)
+        _, lut = ops.hist_tables(gray)
+    else:
+        g5 = ops.gaussian_blur(bgr, 5)
+        gray, _, lut = ops.bgr2gray_hist(bgr)
     sb, eq = ops.sobel_lut(gray, lut)
     return g5, eq, sb
 
@@ -93,9 +99,13 @@ def configs1_one_image(ops, bgr, side_stream=None):
     its input, is enqueued there (forked from and joined to the current stream): one frame leaves the chip mostly idle
     during each kernel's ramp and tail, and under graph capture the fork becomes two branches that overlap."""
     import torch
-    if side_stream is None:
+    one_pass = getattr(ops, "gaussian_blur_gray_one_pass", None)
+    if side_stream is None and one_pass is not None and one_pass(bgr.shape[-3], bgr.shape[-2], 5):
         g5, gray = ops.gaussian_blur_gray(bgr, 5)                # the Gaussian and the gray frame from one read of the colour frame
         _, lut = ops.hist_tables(gray)                           # histogram + table (one launch for one 4K frame)
+    elif side_stream is None:
+        g5 = ops.gaussian_blur(bgr, 5)
+        gray, _, lut = ops.bgr2gray_hist(bgr)
     else:                                                        # forked form: the Gaussian alone on the side stream
         cur = torch.cuda.current_stream()
         side_stream.wait_stream(cur)

@@ -256,6 +256,10 @@ int ipx_gaussian_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
  * (BASELINE.json configs[1]: 5x5 Gaussian of the frame; Sobel and equalizeHist of its gray image): the colour source is
  * read once.  One launch for k = 3 and 5 on rows of whole 16-byte lanes that are at least 4 KiB long (4K / 8K frames);
  * every other case runs the two entry points one after the other.  No halo rows. */
+/* 1 if ipx_gaussian_blur_gray_u8 serves images of this size and kernel size with ONE launch (one read of the colour batch), else 0
+ * (it then runs the two entry points): lets a pipeline choose between it and ipx_bgr2gray_equalize_u8's fused gray + histogram
+ * for the gray half.  Host-only, touches no device.  No counterpart in the reference. */
+int ipx_gaussian_blur_gray_one_pass(int h, int w, int k);
 int ipx_gaussian_blur_gray_u8(void* stream, const uint8_t* src, uint8_t* dst, uint8_t* gray, int n, int h, int w,
                               int64_t src_row_stride, int64_t src_img_stride,
                               int64_t dst_row_stride, int64_t dst_img_stride,

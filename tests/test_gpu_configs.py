@@ -98,6 +98,25 @@ def test_configs1_one_image_step_replayed_from_a_graph(dev):
         np.testing.assert_array_equal(out[2].cpu().numpy(), CO.equalize_hist_u8(CO.bgr2gray_u8(frames[3])))
 
 
+def test_configs1_batch_step_both_forms(dev):
+    """ipx.pipelines.configs1_step on a batch: 4K-wide frames take the form that reads the colour batch once (Gaussian + gray in
+    one launch), 1080p-wide ones the Gaussian and cvtColor + histogram + tables as separate launches; both against the C oracle,
+    and the shape query says which is which."""
+    assert ops.gaussian_blur_gray_one_pass(2160, 3840, 5) and ops.gaussian_blur_gray_one_pass(4320, 7680, 3)
+    assert not ops.gaussian_blur_gray_one_pass(1080, 1920, 5)          # tiles of 192 + 168 lanes: the walker is faster there
+    assert not ops.gaussian_blur_gray_one_pass(2160, 3841, 5)          # rows that are not whole 16-byte lanes
+    assert not ops.gaussian_blur_gray_one_pass(2160, 3840, 7)
+    for n, h, w in ((3, 70, 3840), (3, 90, 1920), (2, 33, 500)):
+        frames = _frames(n, h, w, 13 + w)
+        frames[1][:] = 9                                               # a constant frame
+        g5, eq, sb = P.configs1_step(ops, torch.from_numpy(frames).to(dev))
+        for i in range(n):
+            want_gray = CO.bgr2gray_u8(frames[i])
+            np.testing.assert_array_equal(g5[i].cpu().numpy(), CO.gaussian_blur_u8(frames[i], 5), err_msg=f"{n}x{h}x{w} gaussian {i}")
+            np.testing.assert_array_equal(eq[i, :, :, 0].cpu().numpy(), CO.equalize_hist_u8(want_gray), err_msg=f"{n}x{h}x{w} equalize {i}")
+            np.testing.assert_array_equal(sb[i, :, :, 0].cpu().numpy(), CO.sobel_u8(want_gray), err_msg=f"{n}x{h}x{w} sobel {i}")
+
+
 def test_configs2_full_pipeline_1080p_batch(dev):
     n, h, w = 8, 1080, 1920
     frames = _frames(n, h, w, 1002)
