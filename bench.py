@@ -317,14 +317,14 @@ def main():
     bgr = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, generator=g).to(dev)
 
     STEP_OPS = [  # name, kernels, algorithmic bytes per pixel
-        ("gaussian5_bgr", "sep_pow2_band_kernel<3,5>", 6),
+        ("gaussian5_bgr", "sep_pow2_band_kernel<3,5,true>", 6),
         ("bgr2gray_hist", "gray_hist_kernel<3>+hist_finish_kernel", 4),      # cvtColor + histogram + equalize table (server.py:245-246, first half)
         ("sobel3_gray", "conv3_kernel<SOBEL,1>", 2),
         ("equalize_table_pass", "lut_kernel", 2),                            # cv2.equalizeHist's second half: dst = table[gray]
         # Sobel and that table pass on one read of the gray batch: 1 byte read + 2 written per pixel (2 + 2 as two launches)
         ("sobel3_gray+equalize_table_pass", "conv3_lut_kernel<SOBEL>", 3),
         # the Gaussian and cvtColor on one read of the colour batch: 3 bytes read, 3 + 1 written per pixel (6 + 4 as two launches)
-        ("gaussian5_bgr+bgr2gray", "sep_pow2_band_gray_kernel<5>", 7),
+        ("gaussian5_bgr+bgr2gray", "sep_pow2_band_gray_kernel<5,true>", 7),
         ("hist_tables_gray", "hist_partial_kernel+hist_finish_kernel", 1),   # histograms + equalize tables of the gray batch (1 byte read)
     ]
 
@@ -524,7 +524,7 @@ def main():
             for name, kern, bpp, fn in [
                 ("equalize_hist_gray_one_bin", "hist_partial_kernel+hist_finish_kernel+lut_kernel", 2, lambda: ops.equalize_hist(gray_const)),
                 ("equalize_hist_gray_low_contrast", "hist_partial_kernel+hist_finish_kernel+lut_kernel", 2, lambda: ops.equalize_hist(gray_low)),
-                ("gaussian5_bgr_b2b", "sep_pow2_band_kernel<3,5>", 6, lambda: ops.gaussian_blur(bgr, 5)),
+                ("gaussian5_bgr_b2b", "sep_pow2_band_kernel<3,5,true>", 6, lambda: ops.gaussian_blur(bgr, 5)),
                 ("bgr2gray", "gray_kernel<3,false>", 4, lambda: ops.bgr2gray(bgr)),
                 ("sobel3_gray_b2b", "conv3_kernel<SOBEL,1>", 2, lambda: ops.sobel(gray)),
                 ("box3_gray", "conv3_kernel<BOX,1>", 2, lambda: ops.box3(gray)),

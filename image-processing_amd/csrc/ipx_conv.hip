@@ -561,32 +561,42 @@ __device__ __forceinline__ void pow2_rowpass(us2 (&h)[8], const Win<C, K / 2>& W
     }
 }
 
-// hb = ring of the last K row-pass results, `slot` the newest (source row y + R of output row y): the 16 output bytes
-template <int K>
+// hb = ring of the last K row-pass results, `slot` the newest (source row y + R of output row y): the 16 output bytes.
+// No 16-bit field of the sum overflows (pow2_symmetric_taps checks 255 * sum kx' * sum ky' + rounding < 2^16), so the last two
+// addends -- the outer row and the rounding constant -- go in with ONE 32-bit three-operand add on the packed pair (no carry
+// leaves the low field).  HI8: the shift is 8 (cv2's 5-tap kernel, 16 * [1 4 6 4 1] on both axes), the result byte is the HIGH
+// byte of every field: no shifts, one v_perm_b32 per output dword picks the four bytes -- 16 instructions less per 16 bytes and
+// row than add, add, shift, shift-or (the band kernels issue vector instructions 70 % of their time: DESIGN.md section 4).
+template <int K, bool HI8 = false>
 __device__ __forceinline__ u32x4 pow2_colpass(const us2 (&hb)[K][8], int slot, unsigned short ky1, unsigned short ky2, us2 rnd, us2 sh)
 {
-    us2 o[8];
+    uint32_t o[8];
     // (slot is a compile-time value at every call site -- the callers' loops are unrolled by K -- and so are the ring indices)
     const int s1 = (slot + 1) % K, s2 = (slot + 2) % K, s3 = (slot + 3) % K, s4 = (slot + 4) % K;
+    const uint32_t rnd32 = __builtin_bit_cast(uint32_t, rnd);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {                                // source rows y - R .. y + R = ring slots (slot + 1 + i) % K
-        us2 v;
+        us2 m;
         if (K == 3) {
-            v = (hb[s1][s] + hb[slot][s]) + (hb[s2][s] * ky1 + rnd);
+            m = hb[s2][s] * ky1 + hb[s1][s];
         } else {
-            const us2 oo = hb[s1][s] + hb[slot][s];
             const us2 ii = hb[s2][s] + hb[s4][s];
-            v = (oo + ii * ky1) + (hb[s3][s] * ky2 + rnd);
+            m = hb[s3][s] * ky2 + (ii * ky1 + hb[s1][s]);
         }
-        o[s] = v >> sh;
+        o[s] = __builtin_bit_cast(uint32_t, m) + __builtin_bit_cast(uint32_t, hb[slot][s]) + rnd32;      // v_add3_u32
     }
     u32x4 ov;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ov[k] = pack_fields(o[2 * k], o[2 * k + 1]);
+    for (int k = 0; k < 4; ++k) {
+        if (HI8)
+            ov[k] = __builtin_amdgcn_perm(o[2 * k + 1], o[2 * k], 0x07030501u);     // bytes: even.lo >> 8, odd.lo >> 8, even.hi >> 8, odd.hi >> 8
+        else
+            ov[k] = pack_fields(__builtin_bit_cast(us2, o[2 * k]) >> sh, __builtin_bit_cast(us2, o[2 * k + 1]) >> sh);
+    }
     return ov;
 }
 
-template <int C, int K>
+template <int C, int K, bool HI8 = false>
 __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void sep_pow2_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                        ConvGeom g, Pow2Taps t)
 {
@@ -632,7 +642,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void sep_pow2_kernel(const 
             load_win<C, R>(nx[slot], row(tt + K), b0, g.L);
             const int yo = tt - (K - 1);
             if (yo < nrows) {
-                const u32x4 ov = pow2_colpass<K>(hb, slot, ky1, ky2, rnd, sh);
+                const u32x4 ov = pow2_colpass<K, HI8>(hb, slot, ky1, ky2, rnd, sh);
                 st16_nt(dimg + (int64_t)(y0 + yo) * g.d_row + b0, ov);
             }
         }
@@ -704,7 +714,7 @@ __device__ __forceinline__ void band_win(Win<C, R>& W, const uint8_t* s_tile, in
     }
 }
 
-template <int C, int K>
+template <int C, int K, bool HI8 = false>
 __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                    BandGeom bg, Pow2Taps t)
 {
@@ -745,7 +755,7 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
             const int yo = tt - (K - 1);
             if (yo < nrows) {
                 hrow(hb[slot], tt);
-                const u32x4 ov = pow2_colpass<K>(hb, slot, ky1, ky2, rnd, sh);
+                const u32x4 ov = pow2_colpass<K, HI8>(hb, slot, ky1, ky2, rnd, sh);
                 st16_nt(dimg + (int64_t)(bt.y0 + yo) * g.d_row + b0, ov);
             }
         }
@@ -758,12 +768,12 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
 // 24 x 4K), the block converts the pixels of
 // its 8 output rows whose first byte lies in the tile's own byte range -- groups of 8 pixels = 24 tile bytes (8-byte aligned in
 // LDS; a group reaches at most 23 bytes into the 32-byte halo), three ds_read_b64, a pixel's three bytes as one dword by
-// v_alignbyte_b32 and the Q15 sum as two byte dot products (3735 = 14 * 256 + 151, 19235 = 75 * 256 + 35, 9798 = 38 * 256 + 70:
+// v_alignbyte_b32 and the Q15 sum (weights doubled: the result is byte 2 of the sum) as two byte dot products (7470 = 29 * 256 + 46, 38470 = 150 * 256 + 70, 19596 = 76 * 256 + 140:
 // exact), one 8-byte store per group.  A lane takes one group column through the tile's rows (dealing the (group, row) items
 // over all lanes of the block instead measured slower: 306 against 294 us per 24 x 4K).
 struct GrayOut { uint8_t* p; int64_t row, img; };
 
-template <int K>
+template <int K, bool HI8 = false>
 __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_gray_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                         BandGeom bg, Pow2Taps t, GrayOut gr)
 {
@@ -803,7 +813,7 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_gray_kernel(const ui
             const int yo = tt - (K - 1);
             if (yo < nrows) {
                 hrow(hb[slot], tt);
-                const u32x4 ov = pow2_colpass<K>(hb, slot, ky1, ky2, rnd, sh);
+                const u32x4 ov = pow2_colpass<K, HI8>(hb, slot, ky1, ky2, rnd, sh);
                 st16_nt(dimg + (int64_t)(bt.y0 + yo) * g.d_row + b0, ov);
             }
         }
@@ -818,7 +828,9 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_gray_kernel(const ui
             const int px0 = 8 * jj;
             const uint8_t* tp = s_tile + R * bg.pitch + (24 * jj - bt.xs);
             uint8_t* gp = gr.p + (int64_t)bt.img * gr.img + (int64_t)bt.y0 * gr.row + px0;
-            const uint32_t clo = 151u | (35u << 8) | (70u << 16), chi = 14u | (75u << 8) | (38u << 16);   // B, G, R
+            // Q15 weights DOUBLED (7470 = 29 * 256 + 46, 38470 = 150 * 256 + 70, 19596 = 76 * 256 + 140; rounding 32768): the same
+            // quotient, now (sum >> 16) = byte 2 of the sum, which v_perm_b32 picks while it packs -- no shift per pixel
+            const uint32_t clo = 46u | (70u << 8) | (140u << 16), chi = 29u | (150u << 8) | (76u << 16);   // B, G, R
 #pragma unroll
             for (int r = 0; r < 8; ++r) {                                     // (band tiles are 8 output rows; unrolled: the rows' LDS reads overlap)
                 if (r >= nrows) break;
@@ -829,15 +841,17 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_gray_kernel(const ui
                 for (int i = 0; i < 8; ++i) {
                     const int k = (3 * i) >> 2, sh = (3 * i) & 3;
                     const uint32_t px = sh == 0 ? d[k] : __builtin_amdgcn_alignbyte(d[k + 1 < 6 ? k + 1 : 5], d[k], (uint32_t)sh);
-                    const uint32_t lo = __builtin_amdgcn_udot4(px, clo, 16384u, false);
+                    const uint32_t lo = __builtin_amdgcn_udot4(px, clo, 32768u, false);
                     const uint32_t hi = __builtin_amdgcn_udot4(px, chi, 0u, false);
-                    y[i] = ((hi << 8) + lo) >> 15;
+                    y[i] = (hi << 8) + lo;                                    // gray value in bits 16..23
                 }
-                const u32x2 o = {y[0] | (y[1] << 8) | (y[2] << 16) | (y[3] << 24), y[4] | (y[5] << 8) | (y[6] << 16) | (y[7] << 24)};
+                const uint32_t p01 = __builtin_amdgcn_perm(y[1], y[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(y[3], y[2], 0x06020c0cu);
+                const uint32_t p45 = __builtin_amdgcn_perm(y[5], y[4], 0x0c0c0602u), p67 = __builtin_amdgcn_perm(y[7], y[6], 0x06020c0cu);
+                const u32x2 o = {p01 | p23, p45 | p67};
                 if (px0 + 8 <= g.w) {
                     __builtin_nontemporal_store(o, (u32x2_u*)gp);
                 } else {
-                    for (int i = 0; px0 + i < g.w; ++i) gp[i] = (uint8_t)y[i];
+                    for (int i = 0; px0 + i < g.w; ++i) gp[i] = (uint8_t)(y[i] >> 16);
                 }
                 tp += bg.pitch;
                 gp += gr.row;
@@ -1901,15 +1915,15 @@ bool pow2_symmetric_taps(const uint16_t* kx, const uint16_t* ky, int k, Pow2Taps
     return true;
 }
 
-template <int K>
+template <int K, bool HI8 = false>
 void launch_sep_pow2(hipStream_t st, const uint8_t* src, uint8_t* dst, const ConvGeom& g, int c, const Pow2Taps& t)
 {
     const dim3 grid(conv_grid(g)), block(conv_block(g));
     switch (c) {
-        case 1: hipLaunchKernelGGL((sep_pow2_kernel<1, K>), grid, block, 0, st, src, dst, g, t); break;
-        case 2: hipLaunchKernelGGL((sep_pow2_kernel<2, K>), grid, block, 0, st, src, dst, g, t); break;
-        case 3: hipLaunchKernelGGL((sep_pow2_kernel<3, K>), grid, block, 0, st, src, dst, g, t); break;
-        default: hipLaunchKernelGGL((sep_pow2_kernel<4, K>), grid, block, 0, st, src, dst, g, t); break;
+        case 1: hipLaunchKernelGGL((sep_pow2_kernel<1, K, HI8>), grid, block, 0, st, src, dst, g, t); break;
+        case 2: hipLaunchKernelGGL((sep_pow2_kernel<2, K, HI8>), grid, block, 0, st, src, dst, g, t); break;
+        case 3: hipLaunchKernelGGL((sep_pow2_kernel<3, K, HI8>), grid, block, 0, st, src, dst, g, t); break;
+        default: hipLaunchKernelGGL((sep_pow2_kernel<4, K, HI8>), grid, block, 0, st, src, dst, g, t); break;
     }
 }
 
@@ -1947,16 +1961,16 @@ void launch_band(hipStream_t st, const BandGeom& bg, int r, const uint8_t* src, 
     hipLaunchKernelGGL(kern, dim3(bg.nblocks), dim3((bg.tile_lanes + 63) / 64 * 64), lds, st, src, dst, bg, args...);
 }
 
-template <int K>
+template <int K, bool HI8 = false>
 int launch_sep_pow2_band(hipStream_t st, const uint8_t* src, uint8_t* dst, const ConvGeom& g, int n, int c, const Pow2Taps& t, int band_rows)
 {
     BandGeom bg;
     if (int rc = make_band_geom(bg, g, n, band_rows)) return rc;
     switch (c) {
-        case 1: launch_band<sep_pow2_band_kernel<1, K>>(st, bg, K / 2, src, dst, t); break;
-        case 2: launch_band<sep_pow2_band_kernel<2, K>>(st, bg, K / 2, src, dst, t); break;
-        case 3: launch_band<sep_pow2_band_kernel<3, K>>(st, bg, K / 2, src, dst, t); break;
-        default: launch_band<sep_pow2_band_kernel<4, K>>(st, bg, K / 2, src, dst, t); break;
+        case 1: launch_band<sep_pow2_band_kernel<1, K, HI8>>(st, bg, K / 2, src, dst, t); break;
+        case 2: launch_band<sep_pow2_band_kernel<2, K, HI8>>(st, bg, K / 2, src, dst, t); break;
+        case 3: launch_band<sep_pow2_band_kernel<3, K, HI8>>(st, bg, K / 2, src, dst, t); break;
+        default: launch_band<sep_pow2_band_kernel<4, K, HI8>>(st, bg, K / 2, src, dst, t); break;
     }
     return IPX_OK;
 }
@@ -2197,11 +2211,13 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
 #endif
         if (band > 0) {
             if (int rc = k == 3 ? launch_sep_pow2_band<3>(st, src, dst, g, n, c, pt, band)
-                                : launch_sep_pow2_band<5>(st, src, dst, g, n, c, pt, band)) return rc;
+                       : pt.sh == 8 ? launch_sep_pow2_band<5, true>(st, src, dst, g, n, c, pt, band)
+                                    : launch_sep_pow2_band<5>(st, src, dst, g, n, c, pt, band)) return rc;
             IPX_LAUNCH_CHECK("sep_pow2_band_kernel");
             return IPX_OK;
         }
         if (k == 3) launch_sep_pow2<3>(st, src, dst, g, c, pt);
+        else if (pt.sh == 8) launch_sep_pow2<5, true>(st, src, dst, g, c, pt);     // (cv2's own 5-tap kernel: result = high bytes)
         else launch_sep_pow2<5>(st, src, dst, g, c, pt);
         IPX_LAUNCH_CHECK("sep_pow2_kernel");
         return IPX_OK;
@@ -2311,6 +2327,7 @@ int ipx_gaussian_blur_gray_u8(void* stream, const uint8_t* src, uint8_t* dst, ui
             if (int rc = make_band_geom(bg, g, n, 8)) return rc;
             const GrayOut go{gray, gray_row_stride, gray_img_stride};
             if (k == 3) launch_band<sep_pow2_band_gray_kernel<3>>((hipStream_t)stream, bg, 1, src, dst, pt, go);
+            else if (pt.sh == 8) launch_band<sep_pow2_band_gray_kernel<5, true>>((hipStream_t)stream, bg, 2, src, dst, pt, go);
             else launch_band<sep_pow2_band_gray_kernel<5>>((hipStream_t)stream, bg, 2, src, dst, pt, go);
             IPX_LAUNCH_CHECK("sep_pow2_band_gray_kernel");
             return IPX_OK;

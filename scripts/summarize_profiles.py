@@ -50,7 +50,7 @@ for which, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 bench = json.load(open(os.path.join(src, "bench.json")))
 B = bench["config"]["batch_per_gpu"]
 px = B * 2160 * 3840
-alg_by_prefix = {"sep_pow2_band_kernel<3, 5>": 6, "sep_pow2_kernel<3, 5>": 6, "sep_small_kernel<3, 5>": 6, "conv3_kernel<2, 1>": 2, "conv3_lut_kernel<2>": 3, "sep_pow2_band_gray_kernel<5>": 7, "conv3_kernel<0, 3>": 6, "gray_hist_kernel<3, true>": 4,
+alg_by_prefix = {"sep_pow2_band_kernel<3, 5": 6, "sep_pow2_kernel<3, 5": 6, "sep_small_kernel<3, 5>": 6, "conv3_kernel<2, 1>": 2, "conv3_lut_kernel<2>": 3, "sep_pow2_band_gray_kernel<5": 7, "conv3_kernel<0, 3>": 6, "gray_hist_kernel<3, true>": 4,
                  "gray_kernel<3": 4, "lut_kernel<false, true>": 2, "lut_kernel<true, true>": 2, "hist_partial_kernel<": 1}   # the nt template variants share a row
 
 
@@ -86,7 +86,15 @@ notes = os.path.join(out, f"{name}_pmc_notes.txt")                # hand-written
 if os.path.exists(notes):
     lines += ["", open(notes).read().rstrip()]
 open(os.path.join(out, f"{name}_pmc.md"), "w").write("\n".join(lines) + "\n")
-json.dump({"gaussian5_bgr": (traffic_json.get("sep_pow2_band_kernel<3, 5>") or traffic_json.get("sep_pow2_kernel<3, 5>") or traffic_json.get("sep_small_kernel<3, 5>")),
-           "gaussian5_bgr+bgr2gray": traffic_json.get("sep_pow2_band_gray_kernel<5>"), "batch_per_gpu": B, "per_kernel_bytes": traffic_json,
+def by_prefix(*prefixes):                                        # (template arguments vary: <3, 5> / <3, 5, true>)
+    for pre in prefixes:
+        for k, v in traffic_json.items():
+            if k.startswith(pre):
+                return v
+    return None
+
+
+json.dump({"gaussian5_bgr": by_prefix("sep_pow2_band_kernel<3, 5", "sep_pow2_kernel<3, 5", "sep_small_kernel<3, 5"),
+           "gaussian5_bgr+bgr2gray": by_prefix("sep_pow2_band_gray_kernel<5"), "batch_per_gpu": B, "per_kernel_bytes": traffic_json,
            "source": f"profiles/{name}_pmc.md", "recorded_at": f"round {int(name[1:3])}" if name[1:3].isdigit() else name}, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
