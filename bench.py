@@ -514,13 +514,13 @@ def main():
                                  "enqueued back to back, time per step (a queue of single-frame requests)")
         if args.ops_table:
             gray = ops.bgr2gray(bgr)
-            for _ in range(40):        # the one-image launches above leave the chip idle: its first measurements afterwards read
-                step()                 # 10-20 % high (clocks), so bring it back to the timed region's state first
-            torch.cuda.synchronize()
             # two non-uniform distributions for hist-eq -- every pixel in one bin (the worst case for LDS
             # atomics that collide) and low contrast, clip(N(128, 10))
             gray_const = torch.full_like(gray, 77)
             gray_low = torch.empty(gray.shape, dtype=torch.float32, device=gray.device).normal_(128.0, 10.0).clamp_(0, 255).to(torch.uint8)
+            for _ in range(40):        # the one-image launches above leave the chip idle: its first measurements afterwards read
+                step()                 # 10-20 % high (clocks), so bring it back to the timed region's state first
+            torch.cuda.synchronize()
             for name, kern, bpp, fn in [
                 ("equalize_hist_gray_one_bin", "hist_partial_kernel+hist_finish_kernel+lut_kernel", 2, lambda: ops.equalize_hist(gray_const)),
                 ("equalize_hist_gray_low_contrast", "hist_partial_kernel+hist_finish_kernel+lut_kernel", 2, lambda: ops.equalize_hist(gray_low)),

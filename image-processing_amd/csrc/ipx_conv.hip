@@ -1939,6 +1939,10 @@ int make_band_geom(BandGeom& bg, const ConvGeom& g, int n, int band_rows)
     bg.ntx = (g.nlanes + maxl - 1) / maxl;
     bg.tile_lanes = ((g.nlanes + bg.ntx - 1) / bg.ntx + 63) / 64 * 64;   // near-equal widths in whole waves (1080p BGR: 192 + 168 lanes,
                                                                   // not 256 + 104; 4K BGR: 256 + 256 + 208)
+#ifdef IPX_DEV
+    if (const int rnd = env_int("IPX_BAND_ROUND", 64); rnd != 64)  // development: tile widths in multiples of 16 lanes (4K BGR: 3 x 240)
+        bg.tile_lanes = ((g.nlanes + bg.ntx - 1) / bg.ntx + rnd - 1) / rnd * rnd;
+#endif
     bg.pitch = 16 * bg.tile_lanes + 64;
     const uint64_t nb = (uint64_t)n * bg.nbands * bg.ntx;
     if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "too many band tiles");
