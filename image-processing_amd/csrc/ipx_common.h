@@ -25,6 +25,11 @@ void ipx_clear_error();
 
 // Validates the common (n, h, w, c, strides) arguments of an image entry point.
 // src_c / dst_c are the interleaved channel counts on either side.
+// Neighbourhood operators read pixels around the one they write: a destination that overlaps the source would be read after
+// it was overwritten (cv2 copies in that case; the reference never does it).  IPX_ERR_INVALID if the byte ranges
+// [a, a + extent) and [b, b + extent) of two batches intersect; extent = (n-1) img_stride + (h-1) row_stride + row_bytes.
+int ipx_check_disjoint(const char* fn, const char* what_a, const void* a, int64_t a_row_bytes, int64_t a_row, int64_t a_img,
+                       const char* what_b, const void* b, int64_t b_row_bytes, int64_t b_row, int64_t b_img, int n, int h);
 int ipx_check_image_args(const char* fn, const void* src, const void* dst, int n, int h, int w,
                          int src_c, int dst_c, int64_t src_row_stride, int64_t src_img_stride,
                          int64_t dst_row_stride, int64_t dst_img_stride);

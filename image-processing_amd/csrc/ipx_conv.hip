@@ -1767,6 +1767,8 @@ int make_conv_geom(const char* fn, ConvGeom& g, const uint8_t* src, uint8_t* dst
                    const uint8_t* top, const uint8_t* bot)
 {
     if (int rc = ipx_check_image_args(fn, src, dst, n, h, w, c, c, s_row, s_img, d_row, d_img)) return rc;
+    if (r > 0)
+        if (int rc = ipx_check_disjoint(fn, "source", src, (int64_t)w * c, s_row, s_img, "destination", dst, (int64_t)w * c, d_row, d_img, n, h)) return rc;
     if ((top || bot) && n != 1) return ipx_fail(IPX_ERR_INVALID, "%s: halo rows need n == 1 (got %d)", fn, n);
     if ((int64_t)w * c > (1 << 30)) return ipx_fail(IPX_ERR_UNSUPPORTED, "%s: row of %lld bytes too long", fn, (long long)w * c);
     g.h = h; g.w = w; g.L = w * c;
@@ -2161,7 +2163,8 @@ int ipx_sobel_lut_u8(void* stream, const uint8_t* src, uint8_t* dst_sobel, uint8
     if (!lut_dev) return ipx_fail(IPX_ERR_INVALID, "%s: null table", fn);
     if (lut_stride != 0 && lut_stride < 256) return ipx_fail(IPX_ERR_INVALID, "%s: lut_stride %lld must be 0 or >= 256", fn, (long long)lut_stride);
     if (int rc = ipx_check_image_args(fn, src, dst_lut, n, h, w, 1, 1, s_row, s_img, d_row, d_img)) return rc;
-    if (dst_lut == dst_sobel) return ipx_fail(IPX_ERR_INVALID, "%s: the two destinations are the same buffer", fn);
+    if (int rc = ipx_check_disjoint(fn, "the Sobel destination", dst_sobel, w, d_row, d_img, "the table destination", dst_lut, w, d_row, d_img, n, h)) return rc;
+    if (int rc = ipx_check_disjoint(fn, "source", src, w, s_row, s_img, "the table destination", dst_lut, w, d_row, d_img, n, h)) return rc;
     ConvGeom g;
     if (int rc = make_conv_geom(fn, g, src, dst_sobel, n, h, w, 1, 1, kMaxWavesPerBlock, kConv3U, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
     hipLaunchKernelGGL((conv3_lut_kernel<OP_SOBEL>), dim3(conv_grid(g)), dim3(conv_block(g)), 0, (hipStream_t)stream, src, dst_sobel, dst_lut, g,
@@ -2320,6 +2323,9 @@ int ipx_gaussian_blur_gray_u8(void* stream, const uint8_t* src, uint8_t* dst, ui
     const char* fn = "ipx_gaussian_blur_gray_u8";
     ipx_clear_error();
     if (int rc = ipx_check_image_args(fn, src, gray, n, h, w, 3, 1, s_row, s_img, gray_row_stride, gray_img_stride)) return rc;
+    if (int rc = ipx_check_disjoint(fn, "source", src, 3ll * w, s_row, s_img, "the gray destination", gray, w, gray_row_stride, gray_img_stride, n, h)) return rc;
+    if (dst)
+        if (int rc = ipx_check_disjoint(fn, "the colour destination", dst, 3ll * w, d_row, d_img, "the gray destination", gray, w, gray_row_stride, gray_img_stride, n, h)) return rc;
     uint16_t q[IPX_MAX_GAUSS_K];
     if (int rc = ipx_gauss_kernel_q8(k, 0.0, q)) return rc;
     ConvGeom g;

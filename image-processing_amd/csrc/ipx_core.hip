@@ -19,6 +19,26 @@ int ipx_fail(int code, const char* fmt, ...)
 
 void ipx_clear_error() { g_err[0] = 0; }
 
+int ipx_check_disjoint(const char* fn, const char* what_a, const void* a, int64_t a_row_bytes, int64_t a_row, int64_t a_img,
+                       const char* what_b, const void* b, int64_t b_row_bytes, int64_t b_row, int64_t b_img, int n, int h)
+{
+    if (!a || !b || n <= 0 || h <= 0) return IPX_OK;                 // (null pointers and sizes are reported by the argument check)
+    const uintptr_t a0 = (uintptr_t)a, b0 = (uintptr_t)b;
+    const uintptr_t a1 = a0 + (uintptr_t)((n - 1) * a_img + (h - 1) * a_row + a_row_bytes);
+    const uintptr_t b1 = b0 + (uintptr_t)((n - 1) * b_img + (h - 1) * b_row + b_row_bytes);
+    if (a0 < b1 && b0 < a1) {
+        // two column ranges of ONE pitched buffer (left and right half of a frame, say) interleave without sharing a byte
+        if (a_row == b_row && a_row > 0 && (n == 1 || a_img == b_img) && (n == 1 || a_img % a_row == 0)) {
+            const int64_t d = (int64_t)(b0 % (uintptr_t)a_row) - (int64_t)(a0 % (uintptr_t)a_row);
+            const int64_t c = d >= 0 ? d : d + a_row;                    // b's first column relative to a's, in [0, pitch)
+            if (c >= a_row_bytes && c + b_row_bytes <= a_row) return IPX_OK;
+        }
+        return ipx_fail(IPX_ERR_INVALID, "%s: %s [%p, +%llu) overlaps %s [%p, +%llu): the operator reads neighbouring pixels and cannot work in place",
+                        fn, what_a, a, (unsigned long long)(a1 - a0), what_b, b, (unsigned long long)(b1 - b0));
+    }
+    return IPX_OK;
+}
+
 int ipx_check_image_args(const char* fn, const void* src, const void* dst, int n, int h, int w,
                          int src_c, int dst_c, int64_t src_row_stride, int64_t src_img_stride,
                          int64_t dst_row_stride, int64_t dst_img_stride)

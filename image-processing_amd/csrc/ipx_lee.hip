@@ -510,6 +510,9 @@ extern "C" int ipx_lee_filter_u8(void* stream, const uint8_t* src, uint8_t* dst,
         return rc;
     if (window_size < 1 || window_size / 2 > kMaxK)
         return ipx_fail(IPX_ERR_INVALID, "%s: window_size=%d must be in 1..%d", fn, window_size, 2 * kMaxK + 1);
+    if (window_size / 2 > 0)
+        if (int rc = ipx_check_disjoint(fn, "source", src, w, src_row_stride, src_img_stride, "destination", dst, w, dst_row_stride, dst_img_stride, n, h))
+            return rc;
     const int kk = window_size / 2;                        // server.py:717
     if (kk >= 1 && kk <= 4 && w >= 64) {                   // 3 x 3 ... 9 x 9: the column walker (11 x 11: lee_wide_kernel is faster,
                                                            // 2.14 against 2.90 ms per 24 x 4K; 9 x 9: the walker, 1.43 against 1.85)

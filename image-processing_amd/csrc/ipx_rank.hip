@@ -460,6 +460,8 @@ int make_geom(const char* fn, RankGeom& g, const uint8_t* src, uint8_t* dst, int
               int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, unsigned* blocks)
 {
     if (int rc = ipx_check_image_args(fn, src, dst, n, h, w, 1, 1, s_row, s_img, d_row, d_img)) return rc;
+    if (rx > 0 || ry > 0)
+        if (int rc = ipx_check_disjoint(fn, "source", src, w, s_row, s_img, "destination", dst, w, d_row, d_img, n, h)) return rc;
     g.h = h; g.w = w; g.rx = rx; g.ry = ry;
     g.s_row = s_row; g.s_img = s_img; g.d_row = d_row; g.d_img = d_img;
     g.tiles_x = (w + kTileW - 1) / kTileW;

@@ -12,6 +12,10 @@
  *  - All image pointers are DEVICE pointers (hipMalloc / PyTorch-ROCm tensor.data_ptr()) on the
  *    calling thread's current HIP device.  The caller owns every buffer; the library never frees
  *    caller memory.  src and dst must not overlap unless an entry point says in-place is allowed.
+ *    The neighbourhood operators (3x3 convolutions, separable filters, Lee, median, morphology and their fused forms) CHECK
+ *    this and return IPX_ERR_INVALID: they read pixels around the one they write, so an overlapping destination would be
+ *    read after it was overwritten (cv2 copies in that case; the reference never asks for it).  Two column ranges of one
+ *    pitched buffer (equal strides, e.g. the left and right half of a frame) share no byte and are accepted.
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is enqueued on
  *    it; no entry point synchronises the device except ipx_pairwise_sum_lut_f32, whose result is a
  *    host scalar (it says so).  The library keeps no mutable global state, so

@@ -51,6 +51,18 @@ def test_argument_errors_are_reported_not_thrown():
     assert lib.ipx_box3_u8(None, 1, 1, 1, 0, 4, 1, 4, 16, 4, 16, None, None) == L.IPX_ERR_INVALID
     assert lib.ipx_sobel_u8(None, 1, 1, 1, 4, 4, 5, 20, 80, 20, 80, None, None) == L.IPX_ERR_UNSUPPORTED
     assert lib.ipx_bgr2gray_u8(None, 1, 1, 1, 4, 4, 3, 8, 48, 4, 16) == L.IPX_ERR_INVALID  # stride < row bytes
+    # neighbourhood operators refuse a destination that overlaps the source (rejected before any HIP call; fake addresses)
+    base = 1 << 20
+    assert lib.ipx_box3_u8(None, base, base, 1, 8, 8, 1, 8, 64, 8, 64, None, None) == L.IPX_ERR_INVALID
+    assert b"overlaps" in lib.ipx_last_error()
+    assert lib.ipx_sobel_u8(None, base, base + 16, 1, 8, 8, 1, 8, 64, 8, 64, None, None) == L.IPX_ERR_INVALID      # shifted by two rows
+    assert lib.ipx_gaussian_blur_u8(None, base, base + 63, 1, 8, 8, 1, 8, 64, 8, 64, 5, None, None) == L.IPX_ERR_INVALID
+    assert lib.ipx_median_blur_u8(None, base, base + 8, 1, 8, 8, 8, 64, 8, 64, 3) == L.IPX_ERR_INVALID
+    assert lib.ipx_lee_filter_u8(None, base, base + 32, 2, 8, 8, 8, 64, 8, 64, 5) == L.IPX_ERR_INVALID
+    se = (ctypes.c_uint8 * 9)(*([1] * 9))
+    assert lib.ipx_morph_u8(None, base, base + 4, 1, 8, 8, 8, 64, 8, 64, 0, ctypes.addressof(se), 3, 3) == L.IPX_ERR_INVALID
+    assert lib.ipx_sobel_lut_u8(None, base, base + 4096, base + 4096 + 8, 1, 8, 8, 8, 64, 8, 64, base + 65536, 0) == L.IPX_ERR_INVALID
+    assert lib.ipx_gaussian_blur_gray_u8(None, base, base + 4096, base + 100, 1, 8, 8, 24, 192, 24, 192, 8, 64, 5) == L.IPX_ERR_INVALID
     with pytest.raises(L.IpxError):
         L.call("ipx_equalize_lut_u8", None, None, 1, None)
     # a histogram workspace: null, misaligned, or shorter than its tickets

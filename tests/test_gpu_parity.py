@@ -354,6 +354,29 @@ def test_gaussian_and_gray_in_one_read(dev):
         ops.gaussian_blur_gray(dev_t(rng.integers(0, 256, (8, 64), dtype=np.uint8), dev), 5)
 
 
+def test_neighbourhood_ops_refuse_overlap_but_take_two_halves_of_one_buffer(dev):
+    """A destination that overlaps the source is refused by the neighbourhood operators (they would read pixels already
+    overwritten); the left and right half of ONE pitched buffer interleave in memory without sharing a byte and are accepted."""
+    import ipx._lib as L
+    rng = np.random.default_rng(323)
+    h, w = 37, 200
+    buf = dev_t(rng.integers(0, 256, (h, 2 * w), dtype=np.uint8), dev)
+    src = host(buf)[:, :w].copy()
+    st = torch.cuda.current_stream().cuda_stream
+    L.call("ipx_sobel_u8", st, buf.data_ptr(), buf.data_ptr() + w, 1, h, w, 1, 2 * w, 2 * w * h, 2 * w, 2 * w * h, None, None)
+    L.call("ipx_median_blur_u8", st, buf.data_ptr(), buf.data_ptr() + w, 1, h, w // 2, 2 * w, 2 * w * h, 2 * w, 2 * w * h, 5)
+    torch.cuda.synchronize()
+    got = host(buf)
+    np.testing.assert_array_equal(got[:, :w], src)                                     # the source half is untouched
+    np.testing.assert_array_equal(got[:, w:w + w // 2], O.median_blur_u8(src[:, :w // 2], 5))
+    np.testing.assert_array_equal(got[:, w + w // 2:], O.sobel_u8(src)[:, w // 2:])
+    for shift in (0, 1, w - 1, 2 * w * 3):                                             # same bytes, one column, one pixel short of disjoint, rows below
+        with pytest.raises(L.IpxError):
+            L.call("ipx_box3_u8", st, buf.data_ptr(), buf.data_ptr() + shift, 1, h - 3, w, 1, 2 * w, 2 * w * h, 2 * w, 2 * w * h, None, None)
+    with pytest.raises(L.IpxError):
+        L.call("ipx_lee_filter_u8", st, buf.data_ptr(), buf.data_ptr() + 5, 1, h - 1, w, 2 * w, 2 * w * h, 2 * w, 2 * w * h, 5)
+
+
 def test_hist_tables_without_table_pass(dev):
     """ipx_equalize_hist_u8 with dst = NULL (ops.hist_tables): histograms and equalize tables only, small images (separate
     finish) and images of 65+ blocks (finish inside the counting launch); rejected when no output would take the result."""
