@@ -64,7 +64,9 @@ template <bool NT> __device__ __forceinline__ void st16x(uint8_t* p, u32x4 v) { 
 //   BGR -> gray + histogram       ~420 MB of source (20 frames: 9.18 vs 8.88)
 //   BGR -> gray                   always nt stores (never worse)
 // IPX_NT_BYTES overrides every threshold (0 = always nt, huge = never).
-constexpr uint64_t kNtLut = 300ull << 20, kNtHistThenLut = 440ull << 20, kNtGrayHist = 400ull << 20, kNtAlways = 0;
+//   histogram + tables only       ~600 MB  (2 x the gray batch; the caller's table pass comes next: 128 x 1080p gray, 265 MB, just
+//                                           fits the 256 MiB cache: a six-table pass behind it 285 us (default) vs 420 us (nt))
+constexpr uint64_t kNtLut = 300ull << 20, kNtHistThenLut = 440ull << 20, kNtGrayHist = 400ull << 20, kNtHistOnly = 600ull << 20, kNtAlways = 0;
 bool ipx_use_nt(uint64_t bytes_touched, uint64_t site_threshold);
 
 // gray = (3735 B + 19235 G + 9798 R + 16384) >> 15   (OpenCV RGB2Gray<uchar>, Q15)

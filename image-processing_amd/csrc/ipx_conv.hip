@@ -2302,8 +2302,10 @@ int ipx_sep_filter_q8_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, 
     return rc;
 }
 
-// the shapes and kernel sizes ipx_gaussian_blur_gray_u8 serves with ONE launch (rows of whole 16-byte lanes, >= 4 KiB; a row's band
-// tiles at least 224 lanes wide for 5 taps): the rule of ipx_sep_filter_q8_u8's own choice of band tiles for a BGR batch
+// the shapes and kernel sizes ipx_gaussian_blur_gray_u8 serves with ONE launch: rows of whole 16-byte lanes, >= 4 KiB, a row's band
+// tiles at least 176 lanes wide for 5 taps.  (The Gaussian ALONE takes band tiles from 224 lanes up -- on 1080p BGR rows, two tiles
+// of 180 lanes, its strip walker is 3-5 % faster -- but with the gray image from the same read the band form wins there too:
+// 128 x 1080p, Gaussian + gray + histogram + tables 432 us against 516 us for the walker and cvtColor + histogram, scripts/dev/gray1080.py)
 static bool gaussian_gray_one_pass(int w, int k)
 {
     if (k != 3 && k != 5) return false;
@@ -2311,7 +2313,11 @@ static bool gaussian_gray_one_pass(int w, int k)
     if (w <= 0 || L > (1 << 30) || L % 16 != 0) return false;
     const int nlanes = (int)(L / 16);
     const int ntx = (nlanes + kBandLanes - 1) / kBandLanes;
-    return nlanes >= 256 && (k == 3 || (nlanes + ntx - 1) / ntx >= 224);
+    int min5 = 176;
+#ifdef IPX_DEV
+    min5 = env_int("IPX_GRAY_ONEPASS_MIN", 176);                     // development: A/B of the 5-tap form's narrowest tiles
+#endif
+    return nlanes >= 256 && (k == 3 || (nlanes + ntx - 1) / ntx >= min5);
 }
 
 int ipx_gaussian_blur_gray_one_pass(int h, int w, int k) { return h > 0 && gaussian_gray_one_pass(w, k) ? 1 : 0; }

@@ -468,14 +468,14 @@ int check_hist_args(const char* fn, const uint8_t* src, int n, int h, int w, int
 
 // counting pass + finish: histograms to hist_out and/or tables to lut_out (either may be null)
 int launch_hist(hipStream_t st, const uint8_t* src, int n, int h, int w, int64_t s_row, int64_t s_img,
-                const Workspace& ws, uint32_t* hist_out, uint8_t* lut_out)
+                const Workspace& ws, uint32_t* hist_out, uint8_t* lut_out, uint64_t nt_threshold = kNtHistThenLut)
 {
     HistGeom g = make_geom(h, w, s_row, s_img);
     unsigned bpi = blocks_per_image(n, h, w);
     if (bpi > g.units_per_img) bpi = g.units_per_img;     // strided rows: fewer units than bytes/64K suggests
     const HistTail t = make_tail(ws, n, bpi, hist_out, lut_out);
     // the histogram pass reads what the table pass re-reads right after: keep small batches in the Infinity Cache
-    if (ipx_use_nt(2ull * (uint64_t)n * h * w, kNtHistThenLut))
+    if (ipx_use_nt(2ull * (uint64_t)n * h * w, nt_threshold))
         hipLaunchKernelGGL(hist_partial_kernel<true>, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, t);
     else
         hipLaunchKernelGGL(hist_partial_kernel<false>, dim3(bpi, (unsigned)n), dim3(kThreads), 0, st, src, g, t);
@@ -492,7 +492,8 @@ int equalize_with_workspace(hipStream_t st, const uint8_t* src, uint8_t* dst, in
     Workspace ws;
     workspace_layout(n, h, w, &ws, workspace);
     uint8_t* lut = lut_out_dev ? lut_out_dev : ws.lut;
-    if (int rc = launch_hist(st, src, n, h, w, s_row, s_img, ws, hist_out_dev, lut)) return rc;
+    // (tables only: the caller's own table pass, possibly of several tables, reads the batch next -- leave it in the cache longer)
+    if (int rc = launch_hist(st, src, n, h, w, s_row, s_img, ws, hist_out_dev, lut, dst ? kNtHistThenLut : kNtHistOnly)) return rc;
     if (!dst) return IPX_OK;                                // histograms and tables only: the caller applies the tables
     // the table pass (default cache policy up to kNtHistThenLut bytes: what the histogram pass read is still in the Infinity Cache)
     return ipx_lut_dev_u8((void*)st, src, dst, n, h, w, 1, s_row, s_img, d_row, d_img, lut, 256);

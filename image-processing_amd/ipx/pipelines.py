@@ -52,7 +52,16 @@ def full_pipeline(ops, bgr) -> dict:
     pixel instead of 12); the log table is per image (`s.max()`, server.py:387), built on the device from the histogram the
     gray conversion already produced."""
     import torch
-    gray, hists, eq_lut = ops.bgr2gray_hist(bgr)                # one pass over the colour source: gray8, histograms, equalize tables
+    one_pass = getattr(ops, "gaussian_blur_gray_one_pass", None)
+    if one_pass is not None and one_pass(bgr.shape[-3], bgr.shape[-2], 5):
+        # the Gaussian and the gray batch from ONE read of the colour source, then histograms + equalize tables from the gray batch,
+        # whose loads leave it in the Infinity Cache for the six-table pass (128 x 1080p, scripts/dev/cfg3stages.py: 1040 us per batch
+        # against 1115 us with the Gaussian and cvtColor + histogram as two reads of the colour batch)
+        g5, gray = ops.gaussian_blur_gray(bgr, 5)
+        hists, eq_lut = ops.hist_tables(gray)
+    else:
+        g5 = None
+        gray, hists, eq_lut = ops.bgr2gray_hist(bgr)            # one pass over the colour source: gray8, histograms, equalize tables
     out = {"gray": gray}
     n = hists.reshape(-1, 256).shape[0]
     shared = _dev_const("full_pipeline_tables", gray.device,
@@ -70,7 +79,7 @@ def full_pipeline(ops, bgr) -> dict:
     out["log"] = res[len(FULL_PIPELINE_TABLES)]
     out["histogram_eq"] = res[len(FULL_PIPELINE_TABLES) + 1]
     out["sharpening"] = ops.laplacian_sharpen(bgr)
-    out["gaussian5"] = ops.gaussian_blur(bgr, 5)
+    out["gaussian5"] = g5 if g5 is not None else ops.gaussian_blur(bgr, 5)
     return out
 
 
@@ -79,8 +88,8 @@ def configs1_step(ops, bgr):
     once: the Gaussian and cvtColor share one read of the colour batch (ipx_gaussian_blur_gray_u8), the gray batch's
     histograms and equalize tables come from one read of it, Sobel and equalizeHist's table pass share the next
     (ipx_sobel_lut_u8).  Same pixels as gaussian_blur, bgr2gray_equalize and sobel called one after the other; 11 instead of
-    14 bytes per pixel (scripts/dev/gaussgray.py, sobellut.py).  Frames whose rows the one-pass kernel does not take (1080p; rows that
-    are not whole 16-byte lanes) keep the Gaussian alone and cvtColor + histogram + tables as one launch (13 bytes per pixel)."""
+    14 bytes per pixel (scripts/dev/gaussgray.py, sobellut.py).  Frames whose rows the one-pass kernel does not take (rows shorter than
+    4 KiB or not whole 16-byte lanes) keep the Gaussian alone and cvtColor + histogram + tables as one launch (13 bytes per pixel)."""
     one_pass = getattr(ops, "gaussian_blur_gray_one_pass", None)
     if one_pass is not None and one_pass(bgr.shape[-3], bgr.shape[-2], 5):
         g5, gray = ops.gaussian_blur_gray(bgr, 5)

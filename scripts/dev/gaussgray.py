@@ -9,7 +9,8 @@ import torch
 import ipx.ops as ops
 dev = torch.device("cuda:0")
 B = int(os.environ.get("B", "24"))
-bgr = torch.randint(0, 256, (B, 2160, 3840, 3), dtype=torch.uint8, device=dev)
+H, W = int(os.environ.get("H", "2160")), int(os.environ.get("W", "3840"))
+bgr = torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device=dev)
 def step_a():
     g5 = ops.gaussian_blur(bgr, 5)
     gray, _, lut = ops.bgr2gray_hist(bgr)

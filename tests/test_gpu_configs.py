@@ -99,14 +99,15 @@ def test_configs1_one_image_step_replayed_from_a_graph(dev):
 
 
 def test_configs1_batch_step_both_forms(dev):
-    """ipx.pipelines.configs1_step on a batch: 4K-wide frames take the form that reads the colour batch once (Gaussian + gray in
-    one launch), 1080p-wide ones the Gaussian and cvtColor + histogram + tables as separate launches; both against the C oracle,
-    and the shape query says which is which."""
+    """ipx.pipelines.configs1_step on a batch: 4K- and 1080p-wide frames take the form that reads the colour batch once (Gaussian +
+    gray in one launch), narrower or ragged ones the Gaussian and cvtColor + histogram + tables as separate launches; both against
+    the C oracle, and the shape query says which is which."""
     assert ops.gaussian_blur_gray_one_pass(2160, 3840, 5) and ops.gaussian_blur_gray_one_pass(4320, 7680, 3)
-    assert not ops.gaussian_blur_gray_one_pass(1080, 1920, 5)          # tiles of 192 + 168 lanes: the walker is faster there
+    assert ops.gaussian_blur_gray_one_pass(1080, 1920, 5)              # two tiles of 180 lanes
+    assert not ops.gaussian_blur_gray_one_pass(720, 1280, 5)           # rows shorter than 4 KiB: the strip walker's
     assert not ops.gaussian_blur_gray_one_pass(2160, 3841, 5)          # rows that are not whole 16-byte lanes
     assert not ops.gaussian_blur_gray_one_pass(2160, 3840, 7)
-    for n, h, w in ((3, 70, 3840), (3, 90, 1920), (2, 33, 500)):
+    for n, h, w in ((3, 70, 3840), (3, 90, 1920), (3, 50, 1280), (2, 33, 500)):
         frames = _frames(n, h, w, 13 + w)
         frames[1][:] = 9                                               # a constant frame
         g5, eq, sb = P.configs1_step(ops, torch.from_numpy(frames).to(dev))
