@@ -773,6 +773,53 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_kernel(const uint8_t
 // over all lanes of the block instead measured slower: 306 against 294 us per 24 x 4K).
 struct GrayOut { uint8_t* p; int64_t row, img; };
 
+// The gray phase of a BGR band tile (see sep_pow2_band_gray_kernel): cv2.cvtColor(BGR2GRAY) of the pixels of the tile's output rows
+// whose first byte lies in the tile's own byte range, from the tile in LDS; called by every thread of the block.
+template <int R>
+__device__ __forceinline__ void band_gray_phase(const BandGeom& bg, const BandTile& bt, const GrayOut& gr, const uint8_t* s_tile)
+{
+    const ConvGeom& g = bg.g;
+    const int nrows = bt.y1 - bt.y0;
+    const int own0 = 16 * bt.lane0;
+    const int own1 = 16 * (bt.lane0 + bg.tile_lanes) < g.L ? 16 * (bt.lane0 + bg.tile_lanes) : g.L;
+    const int j0 = (own0 + 23) / 24, j1 = (own1 + 23) / 24;               // groups whose first byte 24 j lies in [own0, own1)
+    const int jj = j0 + (int)threadIdx.x;
+    if (jj < j1) {
+        const int px0 = 8 * jj;
+        const uint8_t* tp = s_tile + R * bg.pitch + (24 * jj - bt.xs);
+        uint8_t* gp = gr.p + (int64_t)bt.img * gr.img + (int64_t)bt.y0 * gr.row + px0;
+        // Q15 weights DOUBLED (7470 = 29 * 256 + 46, 38470 = 150 * 256 + 70, 19596 = 76 * 256 + 140; rounding 32768): the same
+        // quotient, now (sum >> 16) = byte 2 of the sum, which v_perm_b32 picks while it packs -- no shift per pixel
+        const uint32_t clo = 46u | (70u << 8) | (140u << 16), chi = 29u | (150u << 8) | (76u << 16);   // B, G, R
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {                                     // (band tiles are 8 output rows; unrolled: the rows' LDS reads overlap)
+            if (r >= nrows) break;
+            const u32x2 q0 = *(const u32x2*)(tp), q1 = *(const u32x2*)(tp + 8), q2 = *(const u32x2*)(tp + 16);
+            const uint32_t d[6] = {q0[0], q0[1], q1[0], q1[1], q2[0], q2[1]};
+            uint32_t y[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = (3 * i) >> 2, sh = (3 * i) & 3;
+                const uint32_t px = sh == 0 ? d[k] : __builtin_amdgcn_alignbyte(d[k + 1 < 6 ? k + 1 : 5], d[k], (uint32_t)sh);
+                const uint32_t lo = __builtin_amdgcn_udot4(px, clo, 32768u, false);
+                const uint32_t hi = __builtin_amdgcn_udot4(px, chi, 0u, false);
+                y[i] = (hi << 8) + lo;                                    // gray value in bits 16..23
+            }
+            const uint32_t p01 = __builtin_amdgcn_perm(y[1], y[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(y[3], y[2], 0x06020c0cu);
+            const uint32_t p45 = __builtin_amdgcn_perm(y[5], y[4], 0x0c0c0602u), p67 = __builtin_amdgcn_perm(y[7], y[6], 0x06020c0cu);
+            const u32x2 o = {p01 | p23, p45 | p67};
+            if (px0 + 8 <= g.w) {
+                __builtin_nontemporal_store(o, (u32x2_u*)gp);
+            } else {
+                for (int i = 0; px0 + i < g.w; ++i) gp[i] = (uint8_t)(y[i] >> 16);
+            }
+            tp += bg.pitch;
+            gp += gr.row;
+        }
+    }
+}
+
+
 template <int K, bool HI8 = false>
 __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_gray_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                         BandGeom bg, Pow2Taps t, GrayOut gr)
@@ -819,45 +866,71 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_gray_kernel(const ui
         }
     }
     }
-    {   // ---- gray pixels of the tile's own byte range, rows y0 .. y1 - 1 (tile rows R ..)
-        const int own0 = 16 * bt.lane0;
-        const int own1 = 16 * (bt.lane0 + bg.tile_lanes) < g.L ? 16 * (bt.lane0 + bg.tile_lanes) : g.L;
-        const int j0 = (own0 + 23) / 24, j1 = (own1 + 23) / 24;               // groups whose first byte 24 j lies in [own0, own1)
-        const int jj = j0 + (int)threadIdx.x;
-        if (jj < j1) {
-            const int px0 = 8 * jj;
-            const uint8_t* tp = s_tile + R * bg.pitch + (24 * jj - bt.xs);
-            uint8_t* gp = gr.p + (int64_t)bt.img * gr.img + (int64_t)bt.y0 * gr.row + px0;
-            // Q15 weights DOUBLED (7470 = 29 * 256 + 46, 38470 = 150 * 256 + 70, 19596 = 76 * 256 + 140; rounding 32768): the same
-            // quotient, now (sum >> 16) = byte 2 of the sum, which v_perm_b32 picks while it packs -- no shift per pixel
-            const uint32_t clo = 46u | (70u << 8) | (140u << 16), chi = 29u | (150u << 8) | (76u << 16);   // B, G, R
+    band_gray_phase<R>(bg, bt, gr, s_tile);
+}
+
+// THREE outputs from one BGR band tile: cv2's 5-tap Gaussian, the Laplacian sharpening of server.py:270-276 (clip(5c - n - s - e - w),
+// Conv3<OP_SHARPEN>: the same row features and vertical combine as conv3_kernel's) and the gray image.  BASELINE.json configs[2] runs
+// all three on every colour frame -- three reads of the colour batch (4 + 6 + 6 bytes per pixel) become one (3 + 3 + 3 + 1).  The walk
+// over the tile's 12 rows is unrolled completely (band tiles are 8 output rows), so the ring of 5 Gaussian row results and the ring
+// of 3 sharpening row features are both indexed statically; tile row t is the Gaussian's newest row for output row t - 4 and the
+// sharpening's lower neighbour for output row t - 3.
+struct SharpOut { uint8_t* p; int64_t row, img; };
+
+template <bool HI8>
+__global__ __launch_bounds__(kBandLanes) void gauss5_sharpen_gray_band_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                                              BandGeom bg, Pow2Taps t, GrayOut gr, SharpOut sp)
+{
+    constexpr int C = 3, K = 5, R = 2, kRows = 8 + 2 * R;
+    typedef Win<C, R> WR;
+    typedef Conv3<OP_SHARPEN, C> Sh;
+    constexpr int HD = WR::HD;
+    static_assert(HD == 2 && Win<C, 1>::HD == 1, "window layouts this kernel converts between");
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_tile[];
+    const ConvGeom& g = bg.g;
+    const BandTile bt = band_stage<R>(bg, src, s_tile);
+    const int gl = bt.lane0 + (int)threadIdx.x;
+    if (!((int)threadIdx.x >= bg.tile_lanes || gl >= g.nlanes)) {
+        const int b0 = 16 * gl;
+        const bool first = b0 == 0, last = b0 + 16 == g.L;
+        const int off = b0 - bt.xs;
+        const int lo = (b0 >= 4 * HD ? b0 - 4 * HD : b0) - bt.xs;
+        const int hi = (b0 + 16 + 4 * HD <= g.L ? b0 + 16 : b0 + 16 - 4 * HD) - bt.xs;
+        uint8_t* dimg = dst + (int64_t)bt.img * g.d_img + (int64_t)bt.y0 * g.d_row + b0;
+        uint8_t* simg = sp.p + (int64_t)bt.img * sp.img + (int64_t)bt.y0 * sp.row + b0;
+        const unsigned short kx1 = (unsigned short)t.kx1, kx2 = (unsigned short)t.kx2;
+        const unsigned short ky1 = (unsigned short)t.ky1, ky2 = (unsigned short)t.ky2;
+        const us2 rnd = {(unsigned short)t.rnd, (unsigned short)t.rnd};
+        const us2 sh = {(unsigned short)t.sh, (unsigned short)t.sh};
+        us2 hb[K][8];
+        typename Sh::Feat F[3];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {                                     // (band tiles are 8 output rows; unrolled: the rows' LDS reads overlap)
-                if (r >= nrows) break;
-                const u32x2 q0 = *(const u32x2*)(tp), q1 = *(const u32x2*)(tp + 8), q2 = *(const u32x2*)(tp + 16);
-                const uint32_t d[6] = {q0[0], q0[1], q1[0], q1[1], q2[0], q2[1]};
-                uint32_t y[8];
+        for (int tt = 0; tt < kRows; ++tt) {
+            if (tt < bt.rows_in) {                                            // (a last band of fewer than 8 rows)
+                WR W;
+                band_win<C, R>(W, s_tile, bg.pitch, tt, off, lo, hi);
+                fix_edges<C, R>(W, first, last);
+                pow2_rowpass<C, K>(hb[tt % K], W, kx1, kx2);
+                if (tt >= 1 && tt <= kRows - 2) {                             // rows that are a centre or a neighbour of the 3 x 3 operator
+                    Win<C, 1> W1;
+                    W1.w[0] = W.w[1];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int k = (3 * i) >> 2, sh = (3 * i) & 3;
-                    const uint32_t px = sh == 0 ? d[k] : __builtin_amdgcn_alignbyte(d[k + 1 < 6 ? k + 1 : 5], d[k], (uint32_t)sh);
-                    const uint32_t lo = __builtin_amdgcn_udot4(px, clo, 32768u, false);
-                    const uint32_t hi = __builtin_amdgcn_udot4(px, chi, 0u, false);
-                    y[i] = (hi << 8) + lo;                                    // gray value in bits 16..23
+                    for (int i = 0; i < 4; ++i) W1.w[1 + i] = W.w[2 + i];
+                    W1.w[5] = W.w[6];
+                    Sh::feat(F[tt % 3], W1);
                 }
-                const uint32_t p01 = __builtin_amdgcn_perm(y[1], y[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(y[3], y[2], 0x06020c0cu);
-                const uint32_t p45 = __builtin_amdgcn_perm(y[5], y[4], 0x0c0c0602u), p67 = __builtin_amdgcn_perm(y[7], y[6], 0x06020c0cu);
-                const u32x2 o = {p01 | p23, p45 | p67};
-                if (px0 + 8 <= g.w) {
-                    __builtin_nontemporal_store(o, (u32x2_u*)gp);
-                } else {
-                    for (int i = 0; px0 + i < g.w; ++i) gp[i] = (uint8_t)(y[i] >> 16);
+                if (tt >= K - 1) {
+                    const u32x4 ov = pow2_colpass<K, HI8>(hb, tt % K, ky1, ky2, rnd, sh);
+                    st16_nt(dimg + (int64_t)(tt - (K - 1)) * g.d_row, ov);
                 }
-                tp += bg.pitch;
-                gp += gr.row;
+                if (tt >= 3 && tt + 1 < bt.rows_in) {                         // sharpening of output row tt - 3: tile rows tt - 2, tt - 1, tt
+                    const u32x4 so = Sh::out(F[(tt + 1) % 3], F[(tt + 2) % 3], F[tt % 3]);
+                    st16_nt(simg + (int64_t)(tt - 3) * sp.row, so);
+                }
             }
         }
     }
+    band_gray_phase<R>(bg, bt, gr, s_tile);
 }
 
 // The 3 x 3 operators on the same band tiles (sharpen / box / Sobel on BGR frames: rows of >= 4 KiB).
@@ -2352,6 +2425,41 @@ int ipx_gaussian_blur_gray_u8(void* stream, const uint8_t* src, uint8_t* dst, ui
     // every other shape or kernel size: the two entry points one after the other
     if (int rc = ipx_gaussian_blur_u8(stream, src, dst, n, h, w, 3, s_row, s_img, d_row, d_img, k, nullptr, nullptr)) return rc;
     return ipx_bgr2gray_u8(stream, src, gray, n, h, w, 3, s_row, s_img, gray_row_stride, gray_img_stride);
+}
+
+int ipx_gaussian_sharpen_gray_u8(void* stream, const uint8_t* src, uint8_t* dst_gauss, uint8_t* dst_sharp, uint8_t* gray, int n, int h, int w,
+                                 int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img,
+                                 int64_t gray_row_stride, int64_t gray_img_stride, int k)
+{
+    const char* fn = "ipx_gaussian_sharpen_gray_u8";
+    ipx_clear_error();
+    if (int rc = ipx_check_image_args(fn, src, gray, n, h, w, 3, 1, s_row, s_img, gray_row_stride, gray_img_stride)) return rc;
+    if (int rc = ipx_check_image_args(fn, src, dst_sharp, n, h, w, 3, 3, s_row, s_img, d_row, d_img)) return rc;
+    if (int rc = ipx_check_disjoint(fn, "source", src, 3ll * w, s_row, s_img, "the sharpened destination", dst_sharp, 3ll * w, d_row, d_img, n, h)) return rc;
+    if (int rc = ipx_check_disjoint(fn, "source", src, 3ll * w, s_row, s_img, "the gray destination", gray, w, gray_row_stride, gray_img_stride, n, h)) return rc;
+    if (int rc = ipx_check_disjoint(fn, "the sharpened destination", dst_sharp, 3ll * w, d_row, d_img, "the gray destination", gray, w, gray_row_stride, gray_img_stride, n, h)) return rc;
+    if (dst_gauss) {
+        if (int rc = ipx_check_disjoint(fn, "the blurred destination", dst_gauss, 3ll * w, d_row, d_img, "the sharpened destination", dst_sharp, 3ll * w, d_row, d_img, n, h)) return rc;
+        if (int rc = ipx_check_disjoint(fn, "the blurred destination", dst_gauss, 3ll * w, d_row, d_img, "the gray destination", gray, w, gray_row_stride, gray_img_stride, n, h)) return rc;
+    }
+    uint16_t q[IPX_MAX_GAUSS_K];
+    if (int rc = ipx_gauss_kernel_q8(k, 0.0, q)) return rc;
+    ConvGeom g;
+    Pow2Taps pt;
+    if (k == 5 && pow2_symmetric_taps(q, q, k, &pt) && gaussian_gray_one_pass(w, k)) {
+        if (int rc = make_conv_geom(fn, g, src, dst_gauss, n, h, w, 3, 2, kMaxWavesPerBlock, k + 1, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
+        BandGeom bg;
+        if (int rc = make_band_geom(bg, g, n, 8)) return rc;
+        const GrayOut go{gray, gray_row_stride, gray_img_stride};
+        const SharpOut so{dst_sharp, d_row, d_img};
+        if (pt.sh == 8) launch_band<gauss5_sharpen_gray_band_kernel<true>>((hipStream_t)stream, bg, 2, src, dst_gauss, pt, go, so);
+        else launch_band<gauss5_sharpen_gray_band_kernel<false>>((hipStream_t)stream, bg, 2, src, dst_gauss, pt, go, so);
+        IPX_LAUNCH_CHECK("gauss5_sharpen_gray_band_kernel");
+        return IPX_OK;
+    }
+    // every other shape or kernel size: the entry points one after the other
+    if (int rc = ipx_gaussian_blur_gray_u8(stream, src, dst_gauss, gray, n, h, w, s_row, s_img, d_row, d_img, gray_row_stride, gray_img_stride, k)) return rc;
+    return ipx_laplacian_sharpen_u8(stream, src, dst_sharp, n, h, w, 3, s_row, s_img, d_row, d_img, nullptr, nullptr);
 }
 
 int ipx_gaussian_blur_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, int w, int c,

@@ -485,6 +485,19 @@ def gaussian_blur_gray(src: torch.Tensor, k: int):
     return s.restore(out), (gray[0, :, :, 0] if src.ndim == 3 else gray)
 
 
+def gaussian_sharpen_gray(src: torch.Tensor, k: int = 5):
+    """gaussian_blur(src, k), laplacian_sharpen(src) and bgr2gray(src) of one BGR batch in one pass over it
+    (ipx_gaussian_sharpen_gray_u8): returns (blurred, sharpened, gray)."""
+    s = _Img(src)
+    if s.c != 3:
+        raise ValueError("gaussian_sharpen_gray needs 3 (BGR) channels")
+    with _OnDevice(s.t.device):
+        out, sharp, gray = s.like(), s.like(), s.like(1)
+        _lib.call("ipx_gaussian_sharpen_gray_u8", _stream(), s.ptr, out.data_ptr(), sharp.data_ptr(), gray.data_ptr(), s.n, s.h, s.w,
+                  s.row, s.img, s.w * 3, s.w * 3 * s.h, s.w, s.w * s.h, int(k))
+    return s.restore(out), s.restore(sharp), (gray[0, :, :, 0] if src.ndim == 3 else gray)
+
+
 def lee_filter(src: torch.Tensor, window_size: int = 5) -> torch.Tensor:
     """lee_filter(img, window_size) (server.py:711-732): float32 window mean/variance blend on interior pixels."""
     s = _gray(src)

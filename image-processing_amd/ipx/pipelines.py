@@ -54,13 +54,14 @@ def full_pipeline(ops, bgr) -> dict:
     import torch
     one_pass = getattr(ops, "gaussian_blur_gray_one_pass", None)
     if one_pass is not None and one_pass(bgr.shape[-3], bgr.shape[-2], 5):
-        # the Gaussian and the gray batch from ONE read of the colour source, then histograms + equalize tables from the gray batch,
-        # whose loads leave it in the Infinity Cache for the six-table pass (128 x 1080p, scripts/dev/cfg3stages.py: 1040 us per batch
-        # against 1115 us with the Gaussian and cvtColor + histogram as two reads of the colour batch)
-        g5, gray = ops.gaussian_blur_gray(bgr, 5)
+        # the Gaussian, the sharpened and the gray batch from ONE read of the colour source (ipx_gaussian_sharpen_gray_u8: 10 bytes
+        # per pixel instead of 6 + 6 + 4), then histograms + equalize tables from the gray batch, whose loads leave it in the
+        # Infinity Cache for the six-table pass.  128 x 1080p, same-process A/B (scripts/dev/cfg3ab.py): 1110 us per batch with three
+        # reads of the colour batch, 1016 with the Gaussian and the gray batch sharing one, 860 with all three.
+        g5, sharp, gray = ops.gaussian_sharpen_gray(bgr, 5)
         hists, eq_lut = ops.hist_tables(gray)
     else:
-        g5 = None
+        g5 = sharp = None
         gray, hists, eq_lut = ops.bgr2gray_hist(bgr)            # one pass over the colour source: gray8, histograms, equalize tables
     out = {"gray": gray}
     n = hists.reshape(-1, 256).shape[0]
@@ -78,7 +79,7 @@ def full_pipeline(ops, bgr) -> dict:
         out[name] = r
     out["log"] = res[len(FULL_PIPELINE_TABLES)]
     out["histogram_eq"] = res[len(FULL_PIPELINE_TABLES) + 1]
-    out["sharpening"] = ops.laplacian_sharpen(bgr)
+    out["sharpening"] = sharp if sharp is not None else ops.laplacian_sharpen(bgr)
     out["gaussian5"] = g5 if g5 is not None else ops.gaussian_blur(bgr, 5)
     return out
 

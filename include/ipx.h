@@ -269,6 +269,18 @@ int ipx_gaussian_blur_gray_u8(void* stream, const uint8_t* src, uint8_t* dst, ui
                               int64_t dst_row_stride, int64_t dst_img_stride,
                               int64_t gray_row_stride, int64_t gray_img_stride, int k);
 
+/* ipx_gaussian_blur_gray_u8 AND ipx_laplacian_sharpen_u8 of the same BGR batch in one pass -- server.py:428, :270-276 and :517:
+ * dst_gauss = the blurred colour batch, dst_sharp = clip(5c - n - s - e - w) per channel (both n x h x w x 3, sharing the dst
+ * strides), gray = the gray image of the source, each exactly as its own entry point produces it.  For batch pipelines that run all
+ * three on every colour frame (BASELINE.json configs[2]): the colour batch is read once, 10 bytes per pixel instead of 6 + 6 + 4.
+ * One launch for k = 5 on the shapes ipx_gaussian_blur_gray_one_pass accepts; otherwise the entry points one after the other.
+ * No halo rows; the destinations must not overlap the source or each other. */
+int ipx_gaussian_sharpen_gray_u8(void* stream, const uint8_t* src, uint8_t* dst_gauss, uint8_t* dst_sharp, uint8_t* gray,
+                                 int n, int h, int w,
+                                 int64_t src_row_stride, int64_t src_img_stride,
+                                 int64_t dst_row_stride, int64_t dst_img_stride,
+                                 int64_t gray_row_stride, int64_t gray_img_stride, int k);
+
 /* ---- speckle filter ---------------------------------------- */
 
 /* lee_filter(img, window_size) -- server.py:711-732, reached through mode=denoise_manual with

@@ -354,6 +354,35 @@ def test_gaussian_and_gray_in_one_read(dev):
         ops.gaussian_blur_gray(dev_t(rng.integers(0, 256, (8, 64), dtype=np.uint8), dev), 5)
 
 
+def test_gaussian_sharpen_and_gray_in_one_read(dev):
+    """ipx_gaussian_sharpen_gray_u8: the 5-tap Gaussian, the Laplacian sharpening and the gray image of one BGR batch from one read
+    == the three entry points == the oracle: shapes that take the one-launch band-tile form (1080p- and 4K-wide rows, heights around
+    the 8-row tiles, a last band of 1 ... 7 rows), shapes and kernel sizes that fall back, saturating pixels, a row-strided view."""
+    rng = np.random.default_rng(324)
+    for (h, w), k in (((9, 1920), 5), ((16, 1920), 5), ((21, 3840), 5), ((1, 2048), 5), ((2, 1376), 5), ((31, 1184), 5), ((12, 7680), 5),
+                      ((20, 1366), 5), ((12, 300), 5), ((10, 1920), 3), ((9, 2048), 7)):
+        for n in (1, 2):
+            img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+            g5, sh, gray = ops.gaussian_sharpen_gray(dev_t(img, dev), k)
+            for i in range(n):
+                np.testing.assert_array_equal(host(g5)[i], O.gaussian_blur_u8(img[i], k), err_msg=f"gauss {n}x{h}x{w} k={k}")
+                np.testing.assert_array_equal(host(sh)[i], O.laplacian_sharpen_u8(img[i]), err_msg=f"sharpen {n}x{h}x{w} k={k}")
+                np.testing.assert_array_equal(host(gray)[i, :, :, 0], O.bgr2gray_u8(img[i]), err_msg=f"gray {n}x{h}x{w} k={k}")
+    sat = np.zeros((19, 1920, 3), np.uint8); sat[::2, ::3] = 255; sat[5:9, 100:900, 1] = 255        # clip at both ends
+    g5, sh, gray = ops.gaussian_sharpen_gray(dev_t(sat, dev), 5)
+    np.testing.assert_array_equal(host(sh), O.laplacian_sharpen_u8(sat))
+    np.testing.assert_array_equal(host(g5), O.gaussian_blur_u8(sat, 5))
+    np.testing.assert_array_equal(host(gray), O.bgr2gray_u8(sat))
+    big = rng.integers(0, 256, (2, 40, 2000 * 3 + 48), dtype=np.uint8)
+    view = dev_t(big, dev)[:, 3:37, 48:48 + 1920 * 3].unflatten(2, (1920, 3))
+    ref = big[:, 3:37, 48:48 + 1920 * 3].reshape(2, 34, 1920, 3)
+    g5, sh, gray = ops.gaussian_sharpen_gray(view, 5)
+    for i in range(2):
+        np.testing.assert_array_equal(host(g5)[i], O.gaussian_blur_u8(np.ascontiguousarray(ref[i]), 5))
+        np.testing.assert_array_equal(host(sh)[i], O.laplacian_sharpen_u8(np.ascontiguousarray(ref[i])))
+        np.testing.assert_array_equal(host(gray)[i, :, :, 0], O.bgr2gray_u8(np.ascontiguousarray(ref[i])))
+
+
 def test_neighbourhood_ops_refuse_overlap_but_take_two_halves_of_one_buffer(dev):
     """A destination that overlaps the source is refused by the neighbourhood operators (they would read pixels already
     overwritten); the left and right half of ONE pitched buffer interleave in memory without sharing a byte and are accepted."""

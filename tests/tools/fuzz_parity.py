@@ -22,7 +22,7 @@ from ipx import ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=90)
 ap.add_argument("--seed", type=int, default=0)
-ap.add_argument("--ops", default="gray,lut,eq,grayeq,sharpen,box3,sobel,gauss,gauss,lee,median,morph,halo,stats,png,gray16,gaussgray,sobellut")
+ap.add_argument("--ops", default="gray,lut,eq,grayeq,sharpen,box3,sobel,gauss,gauss,lee,median,morph,halo,stats,png,gray16,gaussgray,sobellut,gsg")
 ap.add_argument("--big", action="store_true", help="images of up to ~3 MP and 3000 rows (slower oracle, fewer cases)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
@@ -166,6 +166,15 @@ while time.time() < t_end:
         g5, gray = ops.gaussian_blur_gray(t, k)
         fails += check(f"gaussgray{k}.blur", g5, per_image(lambda x: CO.gaussian_blur_u8(x, k), img), (n, h, w, strided))
         fails += check(f"gaussgray{k}.gray", gray, per_image(CO.bgr2gray_u8, img), (n, h, w, strided))
+    elif op == "gsg":                                        # Gaussian + Laplacian sharpening + gray on one read of a BGR batch
+        k = int(rng.choice([5, 5, 5, 3]))
+        w = int(rng.choice([1184, 1376, 1920, 2048, 2752, 3840])) if rng.random() < 0.7 else max(1, min(w, 1500))
+        h = int(rng.integers(1, 40))
+        t, img = make(n, h, w, 3, strided)
+        g5, sh, gray = ops.gaussian_sharpen_gray(t, k)
+        fails += check(f"gsg{k}.blur", g5, per_image(lambda x: CO.gaussian_blur_u8(x, k), img), (n, h, w, strided))
+        fails += check(f"gsg{k}.sharpen", sh, per_image(CO.laplacian_sharpen_u8, img), (n, h, w, strided))
+        fails += check(f"gsg{k}.gray", gray, per_image(CO.bgr2gray_u8, img), (n, h, w, strided))
     elif op == "sobellut":                                   # Sobel + per-image table pass on one read of a gray batch
         t, img = make(n, h, w, 1, strided)
         tabs = np.stack([rng.permutation(256).astype(np.uint8) for _ in range(n)])
