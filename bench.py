@@ -154,13 +154,22 @@ def run_rowpart(args, torch, dist, ops, dev, rank, world):
         n = min(2048, rows - y)
         local[y:y + n] = torch.randint(0, 256, (n, S), dtype=torch.uint8, generator=g).to(dev)
 
+    fused = args.rowpart_form == "fused"
+
     def step(ev=None):
         if ev is not None:
             ev[0].record()
-        eq = part.equalize_hist(local)
-        if ev is not None:
-            ev[1].record()
-        bx = part.conv3(local, "box3")
+        if fused:                                              # histogram -> all-reduce -> table | halo exchange, then the table pass
+            lut = ops.equalize_lut(part.global_hist(local))    # and the box filter on ONE read of the block (ipx_conv3_lut_u8)
+            if ev is not None:
+                ev[1].record()
+            top, bot = part.exchange_halo(local, 1)
+            bx, eq = ops.conv3_lut("box3", local, lut, top_halo=top, bottom_halo=bot)
+        else:
+            eq = part.equalize_hist(local)
+            if ev is not None:
+                ev[1].record()
+            bx = part.conv3(local, "box3")
         if ev is not None:
             ev[2].record()
         return eq, bx
@@ -198,11 +207,14 @@ def run_rowpart(args, torch, dist, ops, dev, rank, world):
         return None
     px_local = rows * S
     ops_t = {}
-    for j, (name, kern) in enumerate((("equalize_hist_gray", "hist_partial_kernel+hist_finish_kernel+lut_kernel (+ 1 KiB all-reduce)"),
-                                      ("box3_gray", "conv3_kernel<BOX,1> (+ halo rows)"))):
+    stages = ((("hist_tables_gray", "hist_partial_kernel (+ 1 KiB all-reduce) + hist_finish_kernel", 1),
+               ("box3_gray+equalize_table_pass", "conv3_lut_kernel<BOX> (+ halo rows)", 3)) if fused else
+              (("equalize_hist_gray", "hist_partial_kernel+hist_finish_kernel+lut_kernel (+ 1 KiB all-reduce)", 2),
+               ("box3_gray", "conv3_kernel<BOX,1> (+ halo rows)", 2)))
+    for j, (name, kern, bpp) in enumerate(stages):
         s = sum(events[i][j].elapsed_time(events[i][j + 1]) for i in range(args.steps)) / args.steps * 1e-3
-        gbs = px_local * 2 / s / 1e9
-        ops_t[name] = {"kernel": kern, "us_per_step_rank0": round(s * 1e6, 1), "algorithmic_B_per_px": 2, "GBps": round(gbs, 1),
+        gbs = px_local * bpp / s / 1e9
+        ops_t[name] = {"kernel": kern, "us_per_step_rank0": round(s * 1e6, 1), "algorithmic_B_per_px": bpp, "GBps": round(gbs, 1),
                        "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4), "timing": "HIP events around the op (collectives included) in K instrumented steps, rank 0's rows"}
     dom_name = max(ops_t, key=lambda k: ops_t[k]["us_per_step_rank0"])
     dom = ops_t[dom_name]
@@ -232,6 +244,7 @@ def run_rowpart(args, torch, dist, ops, dev, rank, world):
         "dtype": "u8", "data": "synthetic",
         "ranks_seen": dist.get_world_size() if world > 1 else 1, "ms_per_step_per_rank": [round(v, 3) for v in rank_ms],
         "config": {"workload": f"BASELINE.json configs[4]: one {S} x {S} gray image row-partitioned over the ranks, hist-eq + 3x3 box per step",
+                   "form": args.rowpart_form,
                    "rows_per_rank": rows, "image": f"{S}x{S} u8 gray",
                    "messages_per_step_and_rank": f"halo exchange: {S} bytes to and {S} bytes from each neighbour (<= 2 x {S // 1024} KiB each way); "
                                                  "histogram all-reduce(sum): 256 x int32 = 1 KiB",
@@ -239,7 +252,7 @@ def run_rowpart(args, torch, dist, ops, dev, rank, world):
         "roofline": {"bound": "hbm", "kernel": dom["kernel"], "op": dom_name, "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": dom["frac_of_8TBps"], "traffic": None,
                      "traffic_source": "not collected for this workload (profiles/ holds the PMC passes of the pipeline workload)",
-                     "algorithmic_bytes_per_launch": px_local * 2, "launch_us": dom["us_per_step_rank0"]},
+                     "algorithmic_bytes_per_launch": px_local * dom["algorithmic_B_per_px"], "launch_us": dom["us_per_step_rank0"]},
         "cpu_baseline": cpu, "kernels": ops_t,
     }
 
@@ -264,6 +277,9 @@ def main():
                          "BASELINE configs[4]: ONE gray image of --rowpart-size^2 pixels split into contiguous row blocks over the ranks, "
                          "hist-eq (1 KiB histogram all-reduce) + 3x3 box (one halo row exchanged each way) per step (strong scaling)")
     ap.add_argument("--rowpart-size", type=int, default=32768, help="side of the square gray image of --workload rowpart")
+    ap.add_argument("--rowpart-form", default="fused", choices=["fused", "separate"],
+                    help="--workload rowpart: fused = the equalize table pass and the box filter on one read of the row block "
+                         "(ipx_conv3_lut_u8; 4 bytes per pixel and step), separate = equalizeHist, then the filter (5 bytes)")
     args = ap.parse_args()
 
     # --gpus N without a launcher: start N ranks of this script as CHILD processes, before this process touches the GPU

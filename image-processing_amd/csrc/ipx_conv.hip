@@ -2231,17 +2231,29 @@ int ipx_sobel_u8(void* stream, const uint8_t* src, uint8_t* dst, int n, int h, i
 int ipx_sobel_lut_u8(void* stream, const uint8_t* src, uint8_t* dst_sobel, uint8_t* dst_lut, int n, int h, int w,
                      int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* lut_dev, int64_t lut_stride)
 {
-    const char* fn = "ipx_sobel_lut_u8";
+    return ipx_conv3_lut_u8(stream, IPX_CONV3_SOBEL, src, dst_sobel, dst_lut, n, h, w, s_row, s_img, d_row, d_img, lut_dev, lut_stride, nullptr, nullptr);
+}
+
+int ipx_conv3_lut_u8(void* stream, int op, const uint8_t* src, uint8_t* dst_sobel, uint8_t* dst_lut, int n, int h, int w,
+                     int64_t s_row, int64_t s_img, int64_t d_row, int64_t d_img, const uint8_t* lut_dev, int64_t lut_stride,
+                     const uint8_t* top_halo, const uint8_t* bottom_halo)
+{
+    const char* fn = "ipx_conv3_lut_u8";
     ipx_clear_error();
+    if (op != IPX_CONV3_SHARPEN && op != IPX_CONV3_BOX && op != IPX_CONV3_SOBEL)
+        return ipx_fail(IPX_ERR_INVALID, "%s: op=%d (0 = Laplacian sharpening, 1 = 3x3 box, 2 = Sobel)", fn, op);
     if (!lut_dev) return ipx_fail(IPX_ERR_INVALID, "%s: null table", fn);
     if (lut_stride != 0 && lut_stride < 256) return ipx_fail(IPX_ERR_INVALID, "%s: lut_stride %lld must be 0 or >= 256", fn, (long long)lut_stride);
     if (int rc = ipx_check_image_args(fn, src, dst_lut, n, h, w, 1, 1, s_row, s_img, d_row, d_img)) return rc;
     if (int rc = ipx_check_disjoint(fn, "the Sobel destination", dst_sobel, w, d_row, d_img, "the table destination", dst_lut, w, d_row, d_img, n, h)) return rc;
     if (int rc = ipx_check_disjoint(fn, "source", src, w, s_row, s_img, "the table destination", dst_lut, w, d_row, d_img, n, h)) return rc;
     ConvGeom g;
-    if (int rc = make_conv_geom(fn, g, src, dst_sobel, n, h, w, 1, 1, kMaxWavesPerBlock, kConv3U, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
-    hipLaunchKernelGGL((conv3_lut_kernel<OP_SOBEL>), dim3(conv_grid(g)), dim3(conv_block(g)), 0, (hipStream_t)stream, src, dst_sobel, dst_lut, g,
-                       lut_dev, lut_stride);
+    if (int rc = make_conv_geom(fn, g, src, dst_sobel, n, h, w, 1, 1, kMaxWavesPerBlock, kConv3U, s_row, s_img, d_row, d_img, top_halo, bottom_halo)) return rc;
+    const dim3 grid(conv_grid(g)), block(conv_block(g));
+    hipStream_t st = (hipStream_t)stream;
+    if (op == IPX_CONV3_SOBEL) hipLaunchKernelGGL((conv3_lut_kernel<OP_SOBEL>), grid, block, 0, st, src, dst_sobel, dst_lut, g, lut_dev, lut_stride);
+    else if (op == IPX_CONV3_BOX) hipLaunchKernelGGL((conv3_lut_kernel<OP_BOX>), grid, block, 0, st, src, dst_sobel, dst_lut, g, lut_dev, lut_stride);
+    else hipLaunchKernelGGL((conv3_lut_kernel<OP_SHARPEN>), grid, block, 0, st, src, dst_sobel, dst_lut, g, lut_dev, lut_stride);
     IPX_LAUNCH_CHECK("conv3_lut_kernel");
     return IPX_OK;
 }

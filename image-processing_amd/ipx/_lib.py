@@ -53,6 +53,7 @@ SIGNATURES = {
     "ipx_sep_filter_q8_u8": (_i, _IMG + [_i] + _STR + [_vp, _vp, _i, _vp, _vp]),
     "ipx_gaussian_blur_u8": (_i, _IMG + [_i] + _STR + [_i, _vp, _vp]),
     "ipx_gaussian_blur_gray_one_pass": (_i, [_i, _i, _i]),
+    "ipx_conv3_lut_u8": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i] + _STR + [_vp, _i64, _vp, _vp]),
     "ipx_gaussian_sharpen_gray_u8": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i] + _STR + [_i64, _i64, _i]),
     "ipx_gaussian_blur_gray_u8": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i] + _STR + [_i64, _i64, _i]),
     "ipx_lee_filter_u8": (_i, _IMG + _STR + [_i]),

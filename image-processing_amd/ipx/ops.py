@@ -428,6 +428,29 @@ def sobel_lut(src: torch.Tensor, luts: torch.Tensor):
     return s.restore(a), s.restore(b)
 
 
+_CONV3_OPS = {"laplacian_sharpen": 0, "box3": 1, "sobel": 2}
+
+
+def conv3_lut(name: str, src: torch.Tensor, luts: torch.Tensor, top_halo=None, bottom_halo=None):
+    """A 3x3 operator (name in 'laplacian_sharpen', 'box3', 'sobel') and apply_lut_dev(src, luts) of one gray batch in one pass over it
+    (ipx_conv3_lut_u8), with the optional halo rows of a row-partitioned image: returns (filtered, table[src])."""
+    if name not in _CONV3_OPS:
+        raise ValueError(f"conv3_lut: unknown operator {name!r}")
+    s = _gray(src)
+    if luts.dtype != torch.uint8 or luts.device != s.t.device or luts.shape[-1] != 256:
+        raise ValueError("luts: uint8 tensor (..., 256) on the image's device expected")
+    l2 = luts.reshape(-1, 256).contiguous()
+    if l2.shape[0] not in (1, s.n):
+        raise ValueError(f"luts: {l2.shape[0]} tables for {s.n} images")
+    tv, tp = _halo(top_halo, s, 1, "top_halo")
+    bv, bp = _halo(bottom_halo, s, 1, "bottom_halo")
+    with _OnDevice(s.t.device):
+        a, b = s.like(), s.like()
+        _lib.call("ipx_conv3_lut_u8", _stream(), _CONV3_OPS[name], s.ptr, a.data_ptr(), b.data_ptr(), s.n, s.h, s.w,
+                  s.row, s.img, s.w, s.w * s.h, l2.data_ptr(), 256 if l2.shape[0] > 1 else 0, tp, bp)
+    return s.restore(a), s.restore(b)
+
+
 def gauss_kernel_q8(k: int, sigma: float = 0.0) -> np.ndarray:
     """Q0.8 taps cv2.GaussianBlur uses on uint8 (library helper, host side)."""
     if k < 1 or k % 2 == 0 or k > _lib.MAX_GAUSS_K:

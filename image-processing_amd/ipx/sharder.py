@@ -214,6 +214,14 @@ class RowPartition:
         lut = self.ops.equalize_lut(self.global_hist(local))
         return self.ops.apply_lut_dev(local, lut)
 
+    def equalize_hist_and_conv3(self, local, name: str):
+        """equalize_hist(local) and conv3(local, name) of a gray row block with ONE read of it for the table pass and the filter
+        (ipx_conv3_lut_u8): histogram -> all-reduce -> table, halo exchange, then both outputs.  Returns (equalized, filtered)."""
+        lut = self.ops.equalize_lut(self.global_hist(local))
+        top, bot = self.exchange_halo(local, 1)
+        filtered, eq = self.ops.conv3_lut(name, local, lut, top_halo=top, bottom_halo=bot)
+        return eq, filtered
+
     def log_transform(self, local, c: float = 2.0):
         from . import luts
         present = self.global_hist(local).cpu().numpy()

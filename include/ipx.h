@@ -231,6 +231,19 @@ int ipx_sobel_lut_u8(void* stream, const uint8_t* src, uint8_t* dst_sobel, uint8
                      int64_t dst_row_stride, int64_t dst_img_stride,
                      const uint8_t* lut_dev, int64_t lut_stride);
 
+/* The same for any of the three 3x3 operators (op: IPX_CONV3_*; dst_conv = ipx_laplacian_sharpen_u8 / ipx_box3_u8 / ipx_sobel_u8
+ * of src, dst_lut = table_i[src]) and with the optional halo rows of a row-partitioned image (n == 1; SURVEY.md section 8(e):
+ * BASELINE.json configs[4] runs hist-eq and a 3x3 filter on every row block -- after the histogram all-reduce the table pass and
+ * the filter share ONE read of the block, 4 bytes per pixel and step instead of 5). */
+#define IPX_CONV3_SHARPEN 0
+#define IPX_CONV3_BOX 1
+#define IPX_CONV3_SOBEL 2
+int ipx_conv3_lut_u8(void* stream, int op, const uint8_t* src, uint8_t* dst_conv, uint8_t* dst_lut, int n, int h, int w,
+                     int64_t src_row_stride, int64_t src_img_stride,
+                     int64_t dst_row_stride, int64_t dst_img_stride,
+                     const uint8_t* lut_dev, int64_t lut_stride,
+                     const uint8_t* top_halo, const uint8_t* bottom_halo);
+
 /* ---- separable Gaussian ------------------------------------------------------------------- */
 
 /* Host helper: the Q0.8 kernel cv2.GaussianBlur(img,(k,k),sigma) uses on uint8 input (fixed tables

@@ -58,6 +58,10 @@ class OracleOps:
     @staticmethod
     def sobel(t, top_halo=None, bottom_halo=None): return _with_halo(t, top_halo, bottom_halo, 1, O.sobel_u8)
     @staticmethod
+    def conv3_lut(name, t, luts, top_halo=None, bottom_halo=None):
+        f = {"laplacian_sharpen": O.laplacian_sharpen_u8, "box3": O.box3_u8, "sobel": O.sobel_u8}[name]
+        return _with_halo(t, top_halo, bottom_halo, 1, f), _t(_np(luts).reshape(-1, 256)[0][_np(t)])
+    @staticmethod
     def gaussian_blur(t, k, top_halo=None, bottom_halo=None):
         return _with_halo(t, top_halo, bottom_halo, k // 2, lambda a: O.gaussian_blur_u8(a, k))
 

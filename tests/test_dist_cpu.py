@@ -48,6 +48,9 @@ def _worker(rank, world, port, H, ret):
             "gauss5": (part.gaussian_blur(lb, 5).numpy(), O.gaussian_blur_u8(bgr, 5)[part.rows()]),
             "gauss15": (part.gaussian_blur(lg, 15).numpy(), O.gaussian_blur_u8(gray, 15)[part.rows()]),
         }
+        eq2, bx2 = part.equalize_hist_and_conv3(lg, "box3")
+        checks["equalize+box.eq"] = (eq2.numpy(), O.equalize_hist_u8(gray)[part.rows()])
+        checks["equalize+box.box"] = (bx2.numpy(), O.box3_u8(gray)[part.rows()])
         bad = [k for k, (a, b) in checks.items() if not np.array_equal(a, b)]
         # global histogram is the whole image's on every rank
         gh = part.global_hist(lg).numpy()

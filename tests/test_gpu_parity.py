@@ -354,6 +354,33 @@ def test_gaussian_and_gray_in_one_read(dev):
         ops.gaussian_blur_gray(dev_t(rng.integers(0, 256, (8, 64), dtype=np.uint8), dev), 5)
 
 
+def test_conv3_and_table_pass_in_one_read_with_halo_rows(dev):
+    """ipx_conv3_lut_u8: each 3x3 operator and a table pass of one gray batch from one read == the separate entry points == the
+    oracle; with halo rows, a row block of a larger image gives the rows of the whole image's result (the row-partitioned
+    configs[4] step: table pass + filter after the histogram all-reduce)."""
+    rng = np.random.default_rng(325)
+    refs = {"laplacian_sharpen": O.laplacian_sharpen_u8, "box3": O.box3_u8, "sobel": O.sobel_u8}
+    for (n, h, w) in ((1, 1, 1), (2, 5, 43), (1, 33, 44), (3, 40, 333), (1, 70, 4096), (2, 19, 1000)):
+        img = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+        tabs = np.stack([rng.permutation(256).astype(np.uint8) for _ in range(n)])
+        for name, ref in refs.items():
+            f, tb = ops.conv3_lut(name, dev_t(img[..., None], dev), torch.from_numpy(tabs).to(dev))
+            for i in range(n):
+                np.testing.assert_array_equal(host(f)[i, :, :, 0], ref(img[i]), err_msg=f"{name} {n}x{h}x{w}")
+                np.testing.assert_array_equal(host(tb)[i, :, :, 0], tabs[i][img[i]], err_msg=f"table {n}x{h}x{w}")
+    whole = rng.integers(0, 256, (90, 700), dtype=np.uint8)
+    tab = rng.permutation(256).astype(np.uint8)
+    for y0, y1 in ((0, 30), (30, 61), (61, 90)):
+        top = dev_t(whole[y0 - 1:y0], dev) if y0 > 0 else None
+        bot = dev_t(whole[y1:y1 + 1], dev) if y1 < 90 else None
+        for name, ref in refs.items():
+            f, tb = ops.conv3_lut(name, dev_t(whole[y0:y1], dev), torch.from_numpy(tab).to(dev), top_halo=top, bottom_halo=bot)
+            np.testing.assert_array_equal(host(f), ref(whole)[y0:y1], err_msg=f"{name} rows {y0}:{y1}")
+            np.testing.assert_array_equal(host(tb), tab[whole[y0:y1]])
+    with pytest.raises(ValueError):
+        ops.conv3_lut("median", dev_t(whole, dev), torch.from_numpy(tab).to(dev))
+
+
 def test_gaussian_sharpen_and_gray_in_one_read(dev):
     """ipx_gaussian_sharpen_gray_u8: the 5-tap Gaussian, the Laplacian sharpening and the gray image of one BGR batch from one read
     == the three entry points == the oracle: shapes that take the one-launch band-tile form (1080p- and 4K-wide rows, heights around
