@@ -84,7 +84,12 @@ def test_rowpart_workload_two_ranks_on_one_gpu(dev):
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and len(j["ms_per_step_per_rank"]) == 2
     assert j["scaling"] == "strong" and j["config"]["rows_per_rank"] == 1024 and j["value"] > 0
-    assert set(j["kernels"]) == {"equalize_hist_gray", "box3_gray"} and j["roofline"]["frac"] > 0
+    assert set(j["kernels"]) == {"hist_tables_gray", "box3_gray+equalize_table_pass"} and j["roofline"]["frac"] > 0
+    assert j["config"]["form"] == "fused"
+    r = subprocess.run(base + ["--gpus", "2", "--cpu-sample", "0", "--rowpart-form", "separate"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert set(j["kernels"]) == {"equalize_hist_gray", "box3_gray"} and j["ranks_seen"] == 2
     r = subprocess.run(base + ["--gpus", "1", "--cpu-sample", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
