@@ -51,8 +51,14 @@ def main():
             "gauss5_bgr": part.gaussian_blur(lb, 5), "gauss31": part.gaussian_blur(lg, 31), "gauss15_bgr": part.gaussian_blur(lb, 15),
             "gauss7_strided": part.gaussian_blur(lg_strided, 7),
         }
+        eq2, bx2 = part.equalize_hist_and_conv3(lg, "box3")            # the table pass and the filter on one read of the block
+        eq3, sb3 = part.equalize_hist_and_conv3(lg_strided, "sobel")
         torch.cuda.synchronize()
         bad = [k for k in whole if not torch.equal(mine[k], whole[k][part.rows()])]
+        for name, got, want in (("fused.equalize", eq2, whole["equalize"]), ("fused.box3", bx2, whole["box3"]),
+                                ("fused.equalize_strided", eq3, whole["equalize"]), ("fused.sobel_strided", sb3, whole["sobel"])):
+            if not torch.equal(got, want[part.rows()]):
+                bad.append(name)
         gh = part.global_hist(lg)
         if not torch.equal(gh, ops.hist(tg)):
             bad.append("global_hist")
