@@ -262,7 +262,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=24, help="4K RGB frames per GPU per step (round 2: 8: 353 k, 16: 382 k, 20: 400 k, 24: 408 k, 32: 410 k, 48: 397 k MP/s; beyond 24 frames the gray batch no longer fits the Infinity Cache between the kernels that write and read it)")
+    ap.add_argument("--batch", type=int, default=24, help="4K RGB frames per GPU per step (round 3, fused step: 12: 442 k, 16: 450 k, 20: 476 k, 24: 484 k, 28: 486 k, 32: 488 k, 40: 469 k MP/s; round 2: 8: 353 k, 16: 382 k, 24: 408 k, 32: 410 k, 48: 397 k; beyond ~32 frames the gray batch no longer fits the Infinity Cache between the kernels that write and read it)")
     ap.add_argument("--cpu-sample", type=int, default=250, help="passes of the CPU oracle over 4 frames, ~15 s of CPU work, capped at 30 s (0 = skip)")
     ap.add_argument("--order", default="fused", choices=["fused", "fused_tail", "sobel_mid", "table_first", "gauss_last"],
                     help="the step's launches (same results in every form): fused = Gaussian AND gray from one read of the colour batch "
