@@ -87,6 +87,11 @@ int main(int argc,char**argv){
     int nchains=(H+8*NC-1)/(8*NC); unsigned nb=(unsigned)ntx*nchains; char nm[64]; snprintf(nm,64,"chain R=8 halo=2 tiles/block=%d",NC);
     timeit(nm,[&](){ hipLaunchKernelGGL((chain<8,2>),dim3(nb),dim3(256),12*4096,0,s,d,L,H,ntx,nchains,NC,nb); });
   }
+  // tile heights at one tile per block (LDS: (R + 4) x 4 KiB per block)
+#define ONE(RR) { CK(hipFuncSetAttribute((const void*)chain<RR,2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024)); \
+    int nchains=(H+RR-1)/RR; unsigned nb=(unsigned)ntx*nchains; char nm[64]; snprintf(nm,64,"one tile per block, R=%d halo=2",RR); \
+    timeit(nm,[&](){ hipLaunchKernelGGL((chain<RR,2>),dim3(nb),dim3(256),(RR+4)*4096,0,s,d,L,H,ntx,nchains,1,nb); }); }
+  ONE(4) ONE(6) ONE(8) ONE(12) ONE(16) ONE(24)
   // checksum of the last variant against the first
   std::vector<uint8_t> a(1<<20), b(1<<20);
   { int nchains=(H+7)/8; unsigned nb=(unsigned)ntx*nchains; hipLaunchKernelGGL((chain<8,2>),dim3(nb),dim3(256),12*4096,0,s,d,L,H,ntx,nchains,1,nb); CK(hipDeviceSynchronize()); CK(hipMemcpy(a.data(),d+bytes/2,a.size(),hipMemcpyDeviceToHost)); }
