@@ -68,6 +68,18 @@ def test_configs1_single_4k_rgb_gaussian_sobel_equalize(dev):
     gray = ops.bgr2gray(t)
     np.testing.assert_array_equal(ops.sobel(gray).cpu().numpy(), CO.sobel_u8(want_gray))
     np.testing.assert_array_equal(ops.sobel(t).cpu().numpy(), CO.sobel_u8(bgr))
+    # the forms that share one read of the colour frame, on the whole frame (270 bands x 3 tiles, the last tile 208 lanes wide)
+    want_g5, want_sharp = CO.gaussian_blur_u8(bgr, 5), CO.laplacian_sharpen_u8(bgr)
+    g5, gray1 = ops.gaussian_blur_gray(t, 5)
+    np.testing.assert_array_equal(g5.cpu().numpy(), want_g5)
+    np.testing.assert_array_equal(gray1.cpu().numpy(), want_gray)
+    g5, sharp, gray2 = ops.gaussian_sharpen_gray(t, 5)
+    np.testing.assert_array_equal(g5.cpu().numpy(), want_g5)
+    np.testing.assert_array_equal(sharp.cpu().numpy(), want_sharp)
+    np.testing.assert_array_equal(gray2.cpu().numpy(), want_gray)
+    sb, eq2 = ops.sobel_lut(gray2, ops.hist_tables(gray2)[1])
+    np.testing.assert_array_equal(sb.cpu().numpy(), CO.sobel_u8(want_gray))
+    np.testing.assert_array_equal(eq2.cpu().numpy(), CO.equalize_hist_u8(want_gray))
 
 
 def test_configs1_one_image_step_replayed_from_a_graph(dev):
