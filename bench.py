@@ -540,6 +540,7 @@ def main():
             for name, kern, bpp, fn in [
                 ("equalize_hist_gray_one_bin", "hist_partial_kernel+hist_finish_kernel+lut_kernel", 2, lambda: ops.equalize_hist(gray_const)),
                 ("equalize_hist_gray_low_contrast", "hist_partial_kernel+hist_finish_kernel+lut_kernel", 2, lambda: ops.equalize_hist(gray_low)),
+                ("gaussian5+sharpen+gray_bgr", "gauss5_sharpen_gray_band_kernel<true>", 10, lambda: ops.gaussian_sharpen_gray(bgr, 5)),
                 ("gaussian5_bgr_b2b", "sep_pow2_band_kernel<3,5,true>", 6, lambda: ops.gaussian_blur(bgr, 5)),
                 ("bgr2gray", "gray_kernel<3,false>", 4, lambda: ops.bgr2gray(bgr)),
                 ("sobel3_gray_b2b", "conv3_kernel<SOBEL,1>", 2, lambda: ops.sobel(gray)),
