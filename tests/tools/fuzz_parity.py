@@ -229,6 +229,12 @@ while time.time() < t_end:
             got = fn[0](local, top_halo=top, bottom_halo=bot)
             want = per_image(fn[1], img)[0, y0:y1]
         fails += check(f"halo.{which}{k}", got, want, (h, w, c, y0, y1))
+        if which != "gauss" and c == 1:                      # the same block with a table pass on the same read (ipx_conv3_lut_u8)
+            name = {"sharpen": "laplacian_sharpen", "box3": "box3", "sobel": "sobel"}[which]
+            tab = rng.permutation(256).astype(np.uint8)
+            f2, tb = ops.conv3_lut(name, local, torch.from_numpy(tab).to(dev), top_halo=top, bottom_halo=bot)
+            fails += check(f"halo.{which}+table.filter", f2, want, (h, w, c, y0, y1))
+            fails += check(f"halo.{which}+table.table", tb, tab[img[0, y0:y1]], (h, w, c, y0, y1))
     elif op == "stats":
         t, img = make(1, h, w, 1, strided)
         got = ops.denoise_stats(t[0, :, :, 0] if not strided else t[0, :, :, 0].contiguous())
