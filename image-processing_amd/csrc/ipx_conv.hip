@@ -658,6 +658,7 @@ __global__ __launch_bounds__(64 * kMaxWavesPerBlock) void sep_pow2_kernel(const 
 // aligned in LDS); other shapes take the strip walker.
 struct BandGeom { ConvGeom g; int band_rows, nbands, ntx, tile_lanes, pitch; unsigned nblocks; };   // pitch = 16 tile_lanes + 64
 constexpr int kBandLanes = 256;                            // lanes per tile at most (block = tile_lanes rounded up to whole waves)
+constexpr int kMaxBandRows = 10;                          // output rows per tile at most (8 as a rule; make_band_geom)
 
 struct BandTile {                                          // what a block of a band kernel works on (all wave-uniform)
     unsigned img;
@@ -792,29 +793,30 @@ __device__ __forceinline__ void band_gray_phase(const BandGeom& bg, const BandTi
         // quotient, now (sum >> 16) = byte 2 of the sum, which v_perm_b32 picks while it packs -- no shift per pixel
         const uint32_t clo = 46u | (70u << 8) | (140u << 16), chi = 29u | (150u << 8) | (76u << 16);   // B, G, R
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {                                     // (band tiles are 8 output rows; unrolled: the rows' LDS reads overlap)
-            if (r >= nrows) break;
-            const u32x2 q0 = *(const u32x2*)(tp), q1 = *(const u32x2*)(tp + 8), q2 = *(const u32x2*)(tp + 16);
-            const uint32_t d[6] = {q0[0], q0[1], q1[0], q1[1], q2[0], q2[1]};
-            uint32_t y[8];
+        for (int r = 0; r < kMaxBandRows; ++r) {                          // (band tiles are 8 output rows, 9 or 10 for a lone frame; unrolled: the rows' LDS reads overlap)
+            if (r < nrows) {                                                 // (no break: the loop unrolls completely)
+                const u32x2 q0 = *(const u32x2*)(tp), q1 = *(const u32x2*)(tp + 8), q2 = *(const u32x2*)(tp + 16);
+                const uint32_t d[6] = {q0[0], q0[1], q1[0], q1[1], q2[0], q2[1]};
+                uint32_t y[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = (3 * i) >> 2, sh = (3 * i) & 3;
-                const uint32_t px = sh == 0 ? d[k] : __builtin_amdgcn_alignbyte(d[k + 1 < 6 ? k + 1 : 5], d[k], (uint32_t)sh);
-                const uint32_t lo = __builtin_amdgcn_udot4(px, clo, 32768u, false);
-                const uint32_t hi = __builtin_amdgcn_udot4(px, chi, 0u, false);
-                y[i] = (hi << 8) + lo;                                    // gray value in bits 16..23
+                for (int i = 0; i < 8; ++i) {
+                    const int k = (3 * i) >> 2, sh = (3 * i) & 3;
+                    const uint32_t px = sh == 0 ? d[k] : __builtin_amdgcn_alignbyte(d[k + 1 < 6 ? k + 1 : 5], d[k], (uint32_t)sh);
+                    const uint32_t lo = __builtin_amdgcn_udot4(px, clo, 32768u, false);
+                    const uint32_t hi = __builtin_amdgcn_udot4(px, chi, 0u, false);
+                    y[i] = (hi << 8) + lo;                                    // gray value in bits 16..23
+                }
+                const uint32_t p01 = __builtin_amdgcn_perm(y[1], y[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(y[3], y[2], 0x06020c0cu);
+                const uint32_t p45 = __builtin_amdgcn_perm(y[5], y[4], 0x0c0c0602u), p67 = __builtin_amdgcn_perm(y[7], y[6], 0x06020c0cu);
+                const u32x2 o = {p01 | p23, p45 | p67};
+                if (px0 + 8 <= g.w) {
+                    __builtin_nontemporal_store(o, (u32x2_u*)gp);
+                } else {
+                    for (int i = 0; px0 + i < g.w; ++i) gp[i] = (uint8_t)(y[i] >> 16);
+                }
+                tp += bg.pitch;
+                gp += gr.row;
             }
-            const uint32_t p01 = __builtin_amdgcn_perm(y[1], y[0], 0x0c0c0602u), p23 = __builtin_amdgcn_perm(y[3], y[2], 0x06020c0cu);
-            const uint32_t p45 = __builtin_amdgcn_perm(y[5], y[4], 0x0c0c0602u), p67 = __builtin_amdgcn_perm(y[7], y[6], 0x06020c0cu);
-            const u32x2 o = {p01 | p23, p45 | p67};
-            if (px0 + 8 <= g.w) {
-                __builtin_nontemporal_store(o, (u32x2_u*)gp);
-            } else {
-                for (int i = 0; px0 + i < g.w; ++i) gp[i] = (uint8_t)(y[i] >> 16);
-            }
-            tp += bg.pitch;
-            gp += gr.row;
         }
     }
 }
@@ -2002,22 +2004,42 @@ void launch_sep_pow2(hipStream_t st, const uint8_t* src, uint8_t* dst, const Con
     }
 }
 
-int make_band_geom(BandGeom& bg, const ConvGeom& g, int n, int band_rows)
+// halo_r: the filter's radius (the tile holds band_rows + 2 halo_r rows).  one_round: the caller's kernel takes tiles of up to
+// kMaxBandRows output rows, so a launch whose 8-row tiles need a short SECOND round of resident tiles may use taller ones instead.
+int make_band_geom(BandGeom& bg, const ConvGeom& g, int n, int band_rows, int halo_r = 2, bool one_round = false)
 {
     bg.g = g;
-    bg.band_rows = band_rows;
-    bg.nbands = (g.h + band_rows - 1) / band_rows;
     int maxl = kBandLanes;
 #ifdef IPX_DEV
     maxl = env_int("IPX_BAND_LANES", kBandLanes);                 // development: narrower tiles (64, 128, 192)
 #endif
     bg.ntx = (g.nlanes + maxl - 1) / maxl;
-    bg.tile_lanes = ((g.nlanes + bg.ntx - 1) / bg.ntx + 63) / 64 * 64;   // near-equal widths in whole waves (1080p BGR: 192 + 168 lanes,
+    int round = 64;                                               // near-equal widths in whole waves (1080p BGR: 192 + 168 lanes,
                                                                   // not 256 + 104; 4K BGR: 256 + 256 + 208)
+    // ONE frame (a single request): a 4K BGR frame is 270 x 3 = 810 eight-row tiles on 256 CUs x 3 resident tiles = 768 slots, i.e.
+    // a second round of 42 tiles that lasts as long as the first.  Nine-row tiles (240 x 3 = 720) fit one round: 12.4 against
+    // 13.9 us for the 5-tap Gaussian of one frame (scripts/dev/bandrows.py, B = 1).  They need tile widths in multiples of 16 lanes
+    // (3 x 240 instead of 256 + 256 + 208) to keep three tiles per CU in LDS; batches (many rounds anyway) keep 8 rows.
+    if (one_round && band_rows == 8) {
+        const int64_t slots = 3 * 256, per_row_band = (int64_t)n * bg.ntx;
+        const int64_t t8 = per_row_band * ((g.h + 7) / 8);
+        if (t8 > slots && t8 <= slots + slots / 4) {
+            for (int r = 9; r <= kMaxBandRows; ++r) {
+                const int lanes16 = ((g.nlanes + bg.ntx - 1) / bg.ntx + 15) / 16 * 16;
+                if (per_row_band * ((g.h + r - 1) / r) <= slots && (int64_t)(r + 2 * halo_r) * (16 * lanes16 + 64) <= 51200) {
+                    band_rows = r;
+                    round = 16;
+                    break;
+                }
+            }
+        }
+    }
 #ifdef IPX_DEV
-    if (const int rnd = env_int("IPX_BAND_ROUND", 64); rnd != 64)  // development: tile widths in multiples of 16 lanes (4K BGR: 3 x 240)
-        bg.tile_lanes = ((g.nlanes + bg.ntx - 1) / bg.ntx + rnd - 1) / rnd * rnd;
+    round = env_int("IPX_BAND_ROUND", round);                     // development: tile widths in multiples of 16 lanes (4K BGR: 3 x 240)
 #endif
+    bg.band_rows = band_rows;
+    bg.nbands = (g.h + band_rows - 1) / band_rows;
+    bg.tile_lanes = ((g.nlanes + bg.ntx - 1) / bg.ntx + round - 1) / round * round;
     bg.pitch = 16 * bg.tile_lanes + 64;
     const uint64_t nb = (uint64_t)n * bg.nbands * bg.ntx;
     if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "too many band tiles");
@@ -2044,7 +2066,7 @@ template <int K, bool HI8 = false>
 int launch_sep_pow2_band(hipStream_t st, const uint8_t* src, uint8_t* dst, const ConvGeom& g, int n, int c, const Pow2Taps& t, int band_rows)
 {
     BandGeom bg;
-    if (int rc = make_band_geom(bg, g, n, band_rows)) return rc;
+    if (int rc = make_band_geom(bg, g, n, band_rows, K / 2, true)) return rc;
     switch (c) {
         case 1: launch_band<sep_pow2_band_kernel<1, K, HI8>>(st, bg, K / 2, src, dst, t); break;
         case 2: launch_band<sep_pow2_band_kernel<2, K, HI8>>(st, bg, K / 2, src, dst, t); break;
@@ -2058,7 +2080,7 @@ template <int OP>
 int launch_conv3_band(hipStream_t st, const uint8_t* src, uint8_t* dst, const ConvGeom& g, int n, int c, int band_rows)
 {
     BandGeom bg;
-    if (int rc = make_band_geom(bg, g, n, band_rows)) return rc;
+    if (int rc = make_band_geom(bg, g, n, band_rows, 1, true)) return rc;
     switch (c) {
         case 1: launch_band<conv3_band_kernel<OP, 1>>(st, bg, 1, src, dst); break;
         case 2: launch_band<conv3_band_kernel<OP, 2>>(st, bg, 1, src, dst); break;
@@ -2425,7 +2447,7 @@ int ipx_gaussian_blur_gray_u8(void* stream, const uint8_t* src, uint8_t* dst, ui
         if (int rc = make_conv_geom(fn, g, src, dst, n, h, w, 3, k / 2, kMaxWavesPerBlock, k + 1, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
         if (gaussian_gray_one_pass(w, k)) {
             BandGeom bg;
-            if (int rc = make_band_geom(bg, g, n, 8)) return rc;
+            if (int rc = make_band_geom(bg, g, n, 8, k / 2, true)) return rc;
             const GrayOut go{gray, gray_row_stride, gray_img_stride};
             if (k == 3) launch_band<sep_pow2_band_gray_kernel<3>>((hipStream_t)stream, bg, 1, src, dst, pt, go);
             else if (pt.sh == 8) launch_band<sep_pow2_band_gray_kernel<5, true>>((hipStream_t)stream, bg, 2, src, dst, pt, go);
@@ -2461,7 +2483,7 @@ int ipx_gaussian_sharpen_gray_u8(void* stream, const uint8_t* src, uint8_t* dst_
     if (k == 5 && pow2_symmetric_taps(q, q, k, &pt) && gaussian_gray_one_pass(w, k)) {
         if (int rc = make_conv_geom(fn, g, src, dst_gauss, n, h, w, 3, 2, kMaxWavesPerBlock, k + 1, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
         BandGeom bg;
-        if (int rc = make_band_geom(bg, g, n, 8)) return rc;
+        if (int rc = make_band_geom(bg, g, n, 8, 2, false)) return rc;     // (the kernel's walk is unrolled for 8-row tiles)
         const GrayOut go{gray, gray_row_stride, gray_img_stride};
         const SharpOut so{dst_sharp, d_row, d_img};
         if (pt.sh == 8) launch_band<gauss5_sharpen_gray_band_kernel<true>>((hipStream_t)stream, bg, 2, src, dst_gauss, pt, go, so);

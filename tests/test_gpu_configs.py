@@ -110,6 +110,24 @@ def test_configs1_one_image_step_replayed_from_a_graph(dev):
         np.testing.assert_array_equal(out[2].cpu().numpy(), CO.equalize_hist_u8(CO.bgr2gray_u8(frames[3])))
 
 
+def test_lone_frames_take_taller_band_tiles(dev):
+    """A launch whose 8-row band tiles would need a short second round of resident tiles (769 ... 960 tiles on 768 slots: one 4K
+    frame is 810) takes 9- or 10-row tiles of 16-lane-multiple widths instead: the shapes on both sides of that rule, last bands of
+    every length, against the C oracle (5-tap Gaussian alone and with the gray image; the 3 x 3 operators, whose tiles may be 10 rows)."""
+    for n, h, w in ((1, 3333, 2048), (3, 719, 3840), (1, 2400, 3840), (1, 2161, 3840), (2, 1081, 3840), (1, 3073, 2048), (1, 3841, 2048)):
+        frames = _frames(n, h, w, 17 + h)
+        t = torch.from_numpy(frames).to(dev)
+        g5, gray = ops.gaussian_blur_gray(t, 5)
+        g5b, sharp, sob = ops.gaussian_blur(t, 5), ops.laplacian_sharpen(t), ops.sobel(t)
+        for i in range(n):
+            want = CO.gaussian_blur_u8(frames[i], 5)
+            np.testing.assert_array_equal(g5[i].cpu().numpy(), want, err_msg=f"{n}x{h}x{w} gaussian+gray {i}")
+            np.testing.assert_array_equal(g5b[i].cpu().numpy(), want, err_msg=f"{n}x{h}x{w} gaussian {i}")
+            np.testing.assert_array_equal(gray[i, :, :, 0].cpu().numpy(), CO.bgr2gray_u8(frames[i]), err_msg=f"{n}x{h}x{w} gray {i}")
+            np.testing.assert_array_equal(sharp[i].cpu().numpy(), CO.laplacian_sharpen_u8(frames[i]), err_msg=f"{n}x{h}x{w} sharpen {i}")
+            np.testing.assert_array_equal(sob[i].cpu().numpy(), CO.sobel_u8(frames[i]), err_msg=f"{n}x{h}x{w} sobel {i}")
+
+
 def test_configs1_batch_step_both_forms(dev):
     """ipx.pipelines.configs1_step on a batch: 4K- and 1080p-wide frames take the form that reads the colour batch once (Gaussian +
     gray in one launch), narrower or ragged ones the Gaussian and cvtColor + histogram + tables as separate launches; both against
