@@ -2004,9 +2004,25 @@ void launch_sep_pow2(hipStream_t st, const uint8_t* src, uint8_t* dst, const Con
     }
 }
 
-// halo_r: the filter's radius (the tile holds band_rows + 2 halo_r rows).  one_round: the caller's kernel takes tiles of up to
-// kMaxBandRows output rows, so a launch whose 8-row tiles need a short SECOND round of resident tiles may use taller ones instead.
-int make_band_geom(BandGeom& bg, const ConvGeom& g, int n, int band_rows, int halo_r = 2, bool one_round = false)
+// halo_r: the filter's radius (the tile holds band_rows + 2 halo_r rows).  taller: the caller's kernel takes tiles of up to
+// kMaxBandRows output rows instead of `band_rows` (8).
+//  * Tile widths are near-equal multiples of 16 lanes (4K BGR: 3 x 240, not 256 + 256 + 208; the block is the width rounded up to
+//    whole waves): every tile the same work, and 46.8 instead of 49.9 KB of LDS.
+//  * Nine-row tiles where they cost no resident tile per CU (LDS is what limits them): a ninth of the halo rows' row passes and
+//    LDS-DMA less.  24 x 4K BGR (scripts/dev/band9.py): Gaussian + gray 268.9 -> 262.6 us, 3 taps + gray 248.4 -> 242.2; 6 x 8K:
+//    273.7 -> 263.2; the kernels without the gray phase +-0.3 %.
+//  * ONE frame (a single request): a 4K BGR frame is 270 x 3 = 810 eight-row tiles on 256 CUs x 3 resident tiles = 768 slots, i.e.
+//    a second round of 42 tiles that lasts as long as the first; 240 x 3 = 720 nine-row tiles fit one round: 12.4 against 13.9 us
+//    for the 5-tap Gaussian of one frame (scripts/dev/bandrows.py, B = 1).  Launches of 769 ... 960 eight-row tiles take the
+//    shortest taller tile that fits one round, if three of them still fit a CU's LDS.
+static int band_tiles_per_cu(int64_t lds_bytes)
+{
+    const int64_t alloc = (lds_bytes + 1279) / 1280 * 1280;       // (allocation granule observed on this part)
+    const int64_t t = 163840 / alloc;
+    return (int)(t > 8 ? 8 : t);
+}
+
+int make_band_geom(BandGeom& bg, const ConvGeom& g, int n, int band_rows, int halo_r = 2, bool taller = false)
 {
     bg.g = g;
     int maxl = kBandLanes;
@@ -2014,33 +2030,31 @@ int make_band_geom(BandGeom& bg, const ConvGeom& g, int n, int band_rows, int ha
     maxl = env_int("IPX_BAND_LANES", kBandLanes);                 // development: narrower tiles (64, 128, 192)
 #endif
     bg.ntx = (g.nlanes + maxl - 1) / maxl;
-    int round = 64;                                               // near-equal widths in whole waves (1080p BGR: 192 + 168 lanes,
-                                                                  // not 256 + 104; 4K BGR: 256 + 256 + 208)
-    // ONE frame (a single request): a 4K BGR frame is 270 x 3 = 810 eight-row tiles on 256 CUs x 3 resident tiles = 768 slots, i.e.
-    // a second round of 42 tiles that lasts as long as the first.  Nine-row tiles (240 x 3 = 720) fit one round: 12.4 against
-    // 13.9 us for the 5-tap Gaussian of one frame (scripts/dev/bandrows.py, B = 1).  They need tile widths in multiples of 16 lanes
-    // (3 x 240 instead of 256 + 256 + 208) to keep three tiles per CU in LDS; batches (many rounds anyway) keep 8 rows.
-    if (one_round && band_rows == 8) {
-        const int64_t slots = 3 * 256, per_row_band = (int64_t)n * bg.ntx;
+    int round = 16;
+#ifdef IPX_DEV
+    round = env_int("IPX_BAND_ROUND", round);                     // development: A/B of the width rule (64 = whole waves)
+#endif
+    bg.tile_lanes = ((g.nlanes + bg.ntx - 1) / bg.ntx + round - 1) / round * round;
+    bg.pitch = 16 * bg.tile_lanes + 64;
+    if (taller && band_rows == 8) {
+        const int occ8 = band_tiles_per_cu((int64_t)(8 + 2 * halo_r) * bg.pitch);
+        const int64_t slots = (int64_t)occ8 * 256, per_row_band = (int64_t)n * bg.ntx;
         const int64_t t8 = per_row_band * ((g.h + 7) / 8);
-        if (t8 > slots && t8 <= slots + slots / 4) {
+        if (band_tiles_per_cu((int64_t)(9 + 2 * halo_r) * bg.pitch) == occ8) band_rows = 9;
+        if (t8 > slots && t8 <= slots + slots / 4) {              // a short second round of 8-row tiles: fit one round instead
             for (int r = 9; r <= kMaxBandRows; ++r) {
-                const int lanes16 = ((g.nlanes + bg.ntx - 1) / bg.ntx + 15) / 16 * 16;
-                if (per_row_band * ((g.h + r - 1) / r) <= slots && (int64_t)(r + 2 * halo_r) * (16 * lanes16 + 64) <= 51200) {
+                if (per_row_band * ((g.h + r - 1) / r) <= slots && band_tiles_per_cu((int64_t)(r + 2 * halo_r) * bg.pitch) == occ8) {
                     band_rows = r;
-                    round = 16;
                     break;
                 }
             }
         }
-    }
 #ifdef IPX_DEV
-    round = env_int("IPX_BAND_ROUND", round);                     // development: tile widths in multiples of 16 lanes (4K BGR: 3 x 240)
+        band_rows = env_int("IPX_BAND_ROWS_ALL", band_rows);      // development: the tile height of every kernel that takes taller tiles
 #endif
+    }
     bg.band_rows = band_rows;
     bg.nbands = (g.h + band_rows - 1) / band_rows;
-    bg.tile_lanes = ((g.nlanes + bg.ntx - 1) / bg.ntx + round - 1) / round * round;
-    bg.pitch = 16 * bg.tile_lanes + 64;
     const uint64_t nb = (uint64_t)n * bg.nbands * bg.ntx;
     if (nb > 0x7fffffffull) return ipx_fail(IPX_ERR_UNSUPPORTED, "too many band tiles");
     bg.nblocks = (unsigned)nb;
