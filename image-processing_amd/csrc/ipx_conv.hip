@@ -879,11 +879,11 @@ __global__ __launch_bounds__(kBandLanes) void sep_pow2_band_gray_kernel(const ui
 // sharpening's lower neighbour for output row t - 3.
 struct SharpOut { uint8_t* p; int64_t row, img; };
 
-template <bool HI8>
+template <bool HI8, int ROWS = 8>
 __global__ __launch_bounds__(kBandLanes) void gauss5_sharpen_gray_band_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                                               BandGeom bg, Pow2Taps t, GrayOut gr, SharpOut sp)
 {
-    constexpr int C = 3, K = 5, R = 2, kRows = 8 + 2 * R;
+    constexpr int C = 3, K = 5, R = 2, kRows = ROWS + 2 * R;       // ROWS = the tile height make_band_geom chose (8 or 9)
     typedef Win<C, R> WR;
     typedef Conv3<OP_SHARPEN, C> Sh;
     constexpr int HD = WR::HD;
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(kBandLanes) void gauss5_sharpen_gray_band_kernel(co
         typename Sh::Feat F[3];
 #pragma unroll
         for (int tt = 0; tt < kRows; ++tt) {
-            if (tt < bt.rows_in) {                                            // (a last band of fewer than 8 rows)
+            if (tt < bt.rows_in) {                                            // (a last band of fewer rows)
                 WR W;
                 band_win<C, R>(W, s_tile, bg.pitch, tt, off, lo, hi);
                 fix_edges<C, R>(W, first, last);
@@ -2497,11 +2497,16 @@ int ipx_gaussian_sharpen_gray_u8(void* stream, const uint8_t* src, uint8_t* dst_
     if (k == 5 && pow2_symmetric_taps(q, q, k, &pt) && gaussian_gray_one_pass(w, k)) {
         if (int rc = make_conv_geom(fn, g, src, dst_gauss, n, h, w, 3, 2, kMaxWavesPerBlock, k + 1, s_row, s_img, d_row, d_img, nullptr, nullptr)) return rc;
         BandGeom bg;
-        if (int rc = make_band_geom(bg, g, n, 8, 2, false)) return rc;     // (the kernel's walk is unrolled for 8-row tiles)
+        if (int rc = make_band_geom(bg, g, n, 8, 2, true)) return rc;
+        if (bg.band_rows != 8 && bg.band_rows != 9)                        // (the kernel's walk is unrolled per tile height: 8 and 9 exist)
+            if (int rc = make_band_geom(bg, g, n, 8, 2, false)) return rc;
         const GrayOut go{gray, gray_row_stride, gray_img_stride};
         const SharpOut so{dst_sharp, d_row, d_img};
-        if (pt.sh == 8) launch_band<gauss5_sharpen_gray_band_kernel<true>>((hipStream_t)stream, bg, 2, src, dst_gauss, pt, go, so);
-        else launch_band<gauss5_sharpen_gray_band_kernel<false>>((hipStream_t)stream, bg, 2, src, dst_gauss, pt, go, so);
+        hipStream_t st = (hipStream_t)stream;
+        if (pt.sh == 8 && bg.band_rows == 9) launch_band<gauss5_sharpen_gray_band_kernel<true, 9>>(st, bg, 2, src, dst_gauss, pt, go, so);
+        else if (pt.sh == 8) launch_band<gauss5_sharpen_gray_band_kernel<true, 8>>(st, bg, 2, src, dst_gauss, pt, go, so);
+        else if (bg.band_rows == 9) launch_band<gauss5_sharpen_gray_band_kernel<false, 9>>(st, bg, 2, src, dst_gauss, pt, go, so);
+        else launch_band<gauss5_sharpen_gray_band_kernel<false, 8>>(st, bg, 2, src, dst_gauss, pt, go, so);
         IPX_LAUNCH_CHECK("gauss5_sharpen_gray_band_kernel");
         return IPX_OK;
     }
